@@ -1,0 +1,307 @@
+"""Generate ``tests/golden/*.npz`` by IMPORTING THE REFERENCE (build container only).
+
+Run from the repo root:  ``python tests/gen_golden.py``
+
+Recipe: ``albumentations`` / ``cv2`` are imported at module top by the
+reference's ``config.py`` / ``utils.py`` only for data augmentation; they are absent here,
+so ``MagicMock`` stand-ins go into ``sys.modules`` before ``/root/reference/code`` is put on
+``sys.path``.  Nothing from the reference is copied: the fixtures hold OUTPUT numbers only;
+inputs are regenerated from seeds by ``tests/golden_inputs.py``.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+for _m in ("albumentations", "albumentations.pytorch", "cv2"):
+    sys.modules[_m] = MagicMock()
+sys.path.insert(0, "/root/reference/code")
+
+import model as ref_model      # noqa: E402  (the reference)
+import utils as ref_utils      # noqa: E402
+import loss as ref_loss        # noqa: E402
+
+from oracle import net as onet              # noqa: E402
+from tests import golden_inputs as gi       # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def sums(t: torch.Tensor):
+    d = t.double()
+    return np.array([float(d.sum()), float(d.abs().sum())])
+
+
+def ref_net(nc, act, sd):
+    m = ref_model.YOLOv3(num_classes=nc, activation=act)
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+# ------------------------------------------------------------------------ G3 whole network
+def gen_net():
+    out = {}
+    for name, c in gi.NET_CASES.items():
+        sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+        m = ref_net(c["nc"], c["act"], sd).eval()
+        x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+        taps = {}
+        hooks = []
+        mods = dict(m.named_modules())
+        for k in gi.TAP_KEYS:
+            hooks.append(mods[k].register_forward_hook(lambda _m, _i, o, k=k: taps.__setitem__(k, o.detach())))
+        with torch.no_grad():
+            preds = m(x)
+        for h in hooks:
+            h.remove()
+        for i, p in enumerate(preds):
+            p = p.contiguous()
+            if c["full"]:
+                out[f"{name}/p{i}"] = p.numpy()
+            else:
+                out[f"{name}/p{i}_sample"] = p.reshape(-1)[::gi.SAMPLE_STRIDE].numpy().copy()
+            out[f"{name}/p{i}_sums"] = sums(p)
+            print(name, i, tuple(p.shape), float(p.abs().mean()), float(p.abs().max()))
+        for k, t in taps.items():
+            out[f"{name}/tap/{k}"] = t.contiguous().reshape(-1)[::gi.TAP_STRIDE].numpy().copy()
+            out[f"{name}/tapsums/{k}"] = sums(t)
+    np.savez_compressed(os.path.join(OUT, "net_fwd.npz"), **out)
+
+
+# ------------------------------------------------------------------- G1/G2 block goldens
+def gen_blocks():
+    out = {}
+    for i, (cin, cout, k, s, bn, h) in enumerate(gi.BLOCK_CONFIGS):
+        p = gi.block_params(i, cin, cout, k, bn)
+        x = torch.from_numpy(gi.block_input(i, cin, h))
+        for act in (("leaky_relu", "mish") if bn else ("leaky_relu",)):
+            blk = ref_model.CNNBlock(cin, cout, batch_norm_act=bn, activation=act, kernel_size=k,
+                                     stride=s, padding=1 if k == 3 else 0)
+            blk.conv.weight.data.copy_(torch.from_numpy(p["w"]))
+            if bn:
+                blk.batch_norm.weight.data.copy_(torch.from_numpy(p["gamma"]))
+                blk.batch_norm.bias.data.copy_(torch.from_numpy(p["beta"]))
+                blk.batch_norm.running_mean.data.copy_(torch.from_numpy(p["mean"]))
+                blk.batch_norm.running_var.data.copy_(torch.from_numpy(p["var"]))
+            else:
+                blk.conv.bias.data.copy_(torch.from_numpy(p["bias"]))
+            blk.eval()
+            with torch.no_grad():
+                y = blk(x)
+            tag = f"cfg{i}/{act}"
+            out[f"{tag}/eval"] = y.reshape(-1)[::gi.BLOCK_STRIDE].numpy().copy()
+            out[f"{tag}/eval_sums"] = sums(y)
+            if bn:
+                blk.train()
+                xg = x.clone().requires_grad_(True)
+                y = blk(xg)
+                # a fixed upstream gradient pins backward (dgrad / wgrad / BN backward) too
+                gy = torch.from_numpy(np.random.Generator(np.random.PCG64(3000 + i)).standard_normal(
+                    tuple(y.shape), dtype=np.float32))
+                y.backward(gy)
+                out[f"{tag}/train"] = y.detach().reshape(-1)[::gi.BLOCK_STRIDE].numpy().copy()
+                out[f"{tag}/train_sums"] = sums(y.detach())
+                out[f"{tag}/new_mean"] = blk.batch_norm.running_mean.numpy().copy()
+                out[f"{tag}/new_var"] = blk.batch_norm.running_var.numpy().copy()
+                out[f"{tag}/dx"] = xg.grad.reshape(-1)[::gi.BLOCK_STRIDE].numpy().copy()
+                out[f"{tag}/dx_sums"] = sums(xg.grad)
+                out[f"{tag}/dw"] = blk.conv.weight.grad.reshape(-1)[::gi.BLOCK_DW_STRIDE].numpy().copy()
+                out[f"{tag}/dw_sums"] = sums(blk.conv.weight.grad)
+                out[f"{tag}/dgamma"] = blk.batch_norm.weight.grad.numpy().copy()
+                out[f"{tag}/dbeta"] = blk.batch_norm.bias.grad.numpy().copy()
+        print("block", i, (cin, cout, k, s, bn, h))
+    # G2: residual stage and head block
+    rb = ref_model.ResidualBlock(64, num_blocks=2).eval()
+    sp = ref_model.ScalePredictionBlock(128, num_classes=2).eval()
+    g = torch.Generator().manual_seed(77)
+    for mod in (rb, sp):
+        for prm in mod.parameters():
+            prm.data.copy_(torch.randn(prm.shape, generator=g) * (0.08 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0))
+        for nm, buf in mod.named_buffers():
+            if nm.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif nm.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+    xr = torch.randn(2, 64, 12, 12, generator=g)
+    xs = torch.randn(2, 128, 6, 6, generator=g)
+    with torch.no_grad():
+        out["res64x2/x"] = xr.numpy()
+        out["res64x2/y"] = rb(xr).numpy()
+        out["head128/x"] = xs.numpy()
+        out["head128/y"] = sp(xs).contiguous().numpy()
+    for nm, t in list(rb.state_dict().items()):
+        out["res64x2/sd/" + nm] = t.numpy()
+    for nm, t in list(sp.state_dict().items()):
+        out["head128/sd/" + nm] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+
+
+# ------------------------------------------------------------------------ G4 loader map
+def gen_loader():
+    out = {}
+    sd = onet.synth_state_dict(21, 3, 80, gain=1.0)
+    stream = onet.darknet_stream(sd, 3, 80)
+    assert stream.size == 62001757, stream.size
+    with tempfile.TemporaryDirectory() as td:
+        for fname in ("yolov3.weights", "darknet53.conv.74"):
+            path = os.path.join(td, fname)
+            with open(path, "wb") as f:
+                np.array([0, 2, 0, 32013312, 0], np.int32).tofile(f)
+                stream.tofile(f)
+            m = ref_model.YOLOv3(num_classes=80, weights_path=path)
+            before = {k: v.clone() for k, v in m.state_dict().items()}
+            m.load_weights()
+            after = m.state_dict()
+            keys, offs, cnts, loaded = [], [], [], []
+            off = 0
+            # walk in Darknet order (bn: beta,gamma,mean,var then W; head: bias then W)
+            for cv in onet.conv_list(3, 80):
+                p = cv["prefix"]
+                names = ([p + ".batch_norm." + n for n in ("bias", "weight", "running_mean", "running_var")]
+                         if cv["bn"] else [p + ".conv.bias"]) + [p + ".conv.weight"]
+                for nm in names:
+                    t = after[nm]
+                    n = t.numel()
+                    is_loaded = bool(torch.equal(t.reshape(-1), torch.from_numpy(stream[off:off + n])))
+                    changed = not torch.equal(t, before[nm])
+                    assert is_loaded == changed or n == 0, (nm, is_loaded, changed)
+                    keys.append(nm); offs.append(off); cnts.append(n); loaded.append(is_loaded)
+                    off += n
+            assert off == stream.size
+            tag = "full" if fname == "yolov3.weights" else "conv74"
+            out[f"{tag}/keys"] = np.array(keys)
+            out[f"{tag}/offsets"] = np.array(offs, np.int64)
+            out[f"{tag}/counts"] = np.array(cnts, np.int64)
+            out[f"{tag}/loaded"] = np.array(loaded, bool)
+            print(fname, "loaded tensors:", int(np.sum(loaded)), "of", len(loaded),
+                  "last loaded:", [k for k, l in zip(keys, loaded) if l][-1])
+    out["state_dict_keys"] = np.array(list(ref_model.YOLOv3(num_classes=80).state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "loader.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G5 decode
+def gen_decode():
+    out = {}
+    for name in gi.DECODE_CASES:
+        pred, anchors = gi.decode_input(name)
+        p = torch.from_numpy(pred.copy())
+        boxes = ref_utils.cells_to_boxes(p, torch.from_numpy(anchors), gi.DECODE_CASES[name]["g"], is_pred=True)
+        out[f"{name}/boxes"] = np.asarray(boxes, np.float32)
+        out[f"{name}/mutated"] = p.numpy()          # the in-place side effect (utils.py:106-110)
+        # fp16 / bf16 inputs (autocast outputs): values differ, order of ops the same
+        for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+            ph = torch.from_numpy(pred.copy()).to(dt)
+            bh = ref_utils.cells_to_boxes(ph, torch.from_numpy(anchors), gi.DECODE_CASES[name]["g"], is_pred=True)
+            out[f"{name}/boxes_{tag}"] = np.asarray(bh, np.float32)
+    # targets path (is_pred=False)
+    t = torch.from_numpy(gi.synth_targets(2, 96, 2, gi.TRAIN_CASE["anchors"], 55)[2])
+    tb = ref_utils.cells_to_boxes(t, torch.zeros(3, 2), 12, is_pred=False)
+    out["targets_g12/boxes"] = np.asarray(tb, np.float32)
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ G6 NMS
+def rows_to_indices(kept_rows, boxes):
+    """Map the reference's kept BOXES back to indices of the input list (first unused
+    identical row, scanning in input order — identical rows are interchangeable)."""
+    kept = np.asarray(kept_rows, np.float32).reshape(-1, 6)
+    used = np.zeros(len(boxes), bool)
+    idx = []
+    view = boxes.view(np.uint32)
+    for r in kept.view(np.uint32):
+        cand = np.nonzero((view == r).all(1) & ~used)[0]
+        assert cand.size, "kept box not found in the input"
+        idx.append(int(cand[0])); used[cand[0]] = True
+    return np.asarray(idx, np.int64)
+
+
+def gen_nms():
+    import time
+    out = {}
+    for name in gi.NMS_CASES:
+        boxes, iou_thr, obj_thr, fmt = gi.nms_boxes(name)
+        t = time.time()
+        kept = ref_utils.non_max_suppression(boxes.tolist(), iou_thr, obj_thr, fmt)
+        dt = time.time() - t
+        idx = rows_to_indices(kept, boxes)
+        out[f"{name}/keep"] = idx
+        print("nms", name, "n=", len(boxes), "kept=", len(idx), f"{dt:.2f}s")
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **out)
+
+
+# ----------------------------------------------------------------------- G7 train step
+def gen_train():
+    c = gi.TRAIN_CASE
+    out = {}
+    for tag, act in (("leaky", "leaky_relu"), ("mish", "mish")):
+        sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+        m = ref_net(c["nc"], act, sd).train()
+        x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+        tg = [torch.from_numpy(t) for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+        grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+        sa = torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)
+        lf = ref_loss.YOLOLoss()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        opt.zero_grad()
+        preds = m(x)
+        out[f"{tag}/pred_sums"] = np.stack([sums(p.detach()) for p in preds])
+        parts = []
+        for i in range(3):
+            parts.append(torch.stack(lf(preds[i], tg[i].clone(), sa[i])))
+        parts = torch.stack(parts)                      # (3 scales, 4 parts)
+        total = parts.sum()
+        total.backward()
+        out[f"{tag}/loss_parts"] = parts.detach().numpy()
+        out[f"{tag}/loss"] = np.array(float(total))
+        g = {k: p.grad for k, p in m.named_parameters()}
+        for k in ("layers.0.conv.weight", "layers.10.layers.3.1.conv.weight", "layers.15.pred_block.1.conv.bias",
+                  "layers.22.pred_block.1.conv.bias", "layers.29.pred_block.1.conv.bias",
+                  "layers.0.batch_norm.weight", "layers.0.batch_norm.bias", "layers.6.layers.7.1.batch_norm.weight",
+                  "layers.18.conv.weight", "layers.29.pred_block.1.conv.weight"):
+            out[f"{tag}/grad/{k}"] = g[k].reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy().copy() if g[k].numel() > 4096 else g[k].numpy().copy()
+            out[f"{tag}/gradsums/{k}"] = sums(g[k])
+        out[f"{tag}/gradnorm_all"] = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+        out[f"{tag}/rm0"] = m.state_dict()["layers.0.batch_norm.running_mean"].numpy().copy()
+        out[f"{tag}/rv0"] = m.state_dict()["layers.0.batch_norm.running_var"].numpy().copy()
+        opt.step()
+        out[f"{tag}/w0_after_sgd"] = m.state_dict()["layers.0.conv.weight"].numpy().copy()
+        print("train", tag, parts.detach().numpy().round(4).tolist(), float(total))
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+
+
+# -------------------------------------------------------------------------- G8 the KATs
+def gen_kat():
+    out = {}
+    b = torch.tensor([0.5, 0.5, 0.25, 0.25])
+    out["iou_self"] = ref_utils.calc_iou(b, b).numpy()            # utils_test.py:16-20 (0.99998…, not 1.0)
+    pb = [[0, 0.5, 0.5, 0.25, 0.25, 0.9, 0], [0, 0.5, 0.5, 0.1, 0.1, 0.6, 0]]
+    out["map_identical"] = np.array(float(ref_utils.calc_mAP(pb, [r[:] for r in pb])))   # utils_test.py:22-32
+    z = torch.zeros((5, 3, 3, 3, 8))
+    out["c2b_zeros"] = np.asarray(ref_utils.cells_to_boxes(z, torch.tensor([[0.28, 0.22], [0.38, 0.48], [0.9, 0.78]]), 3),
+                                  np.float32)                     # utils_test.py:34-40
+    rng = np.random.Generator(np.random.PCG64(99))
+    a = rng.random((200, 4), dtype=np.float32)
+    c = rng.random((200, 4), dtype=np.float32)
+    out["iou_center"] = ref_utils.calc_iou(torch.from_numpy(a), torch.from_numpy(c), "center").numpy()
+    out["iou_corners"] = ref_utils.calc_iou(torch.from_numpy(a), torch.from_numpy(c), "corners").numpy()
+    out["iou_aligned"] = ref_utils.iou_aligned(torch.from_numpy(a[:, 2:]), torch.from_numpy(c[:, 2:])).numpy()
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat"]
+    for w in which:
+        print("==", w)
+        globals()["gen_" + w]()
