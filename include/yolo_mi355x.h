@@ -1,0 +1,127 @@
+/* yolo_mi355x.h — C ABI of libyolo_mi355x.so (MI355X / gfx950 YOLOv3 hot path).
+ *
+ * The reference (GabeTsai/YOLO-For-Turbines) has no FFI/plugin layer: its boundary is the
+ * Python call surface of code/model.py and code/utils.py. Every entry point
+ * below states which reference routine's arithmetic it replaces. The host-side mirror of the
+ * reference interface (same class / function names) lives in yolo_for_turbines_amd/ and calls
+ * these through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - all data pointers are DEVICE pointers (tensor.data_ptr()); the caller owns every buffer,
+ *    including workspaces; the library allocates nothing and keeps no mutable global state
+ *    except a thread-local error string;
+ *  - `stream` is a hipStream_t passed as void*; every function only enqueues work on it and
+ *    never synchronises the device;
+ *  - return value 0 = ok, negative = error (message: yolo_last_error()).
+ *  - activations are NHWC ("pixel-major"): element (n,h,w,c) of a tensor with channel stride
+ *    `ld` and channel offset `off` lives at ((n*H + h)*W + w)*ld + off + c. A concat buffer is
+ *    simply one allocation with a larger `ld` that several producers write slices of.
+ */
+#ifndef YOLO_MI355X_H
+#define YOLO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_OK 0
+#define YOLO_ERR_ARG (-1)
+#define YOLO_ERR_UNSUPPORTED (-2)
+#define YOLO_ERR_LAUNCH (-3)
+#define YOLO_ERR_WORKSPACE (-4)
+
+enum { YOLO_F32 = 0, YOLO_F16 = 1, YOLO_BF16 = 2 };
+enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY = 1, YOLO_ACT_MISH = 2 };
+/* where the epilogue writes: plain NHWC; NHWC with nearest 2x upsample (each value goes to its
+ * 2x2 destination pixels, replaces nn.Upsample + the first half of torch.cat, model.py:189-191,
+ * 222); or the detection-head layout (B,3,g,g,5+nc) contiguous (replaces the reshape + permute
+ * of ScalePredictionBlock.forward, model.py:145-148; conv channel = a*(5+nc)+k). */
+enum { YOLO_OUT_NHWC = 0, YOLO_OUT_UPSAMPLE2X = 1, YOLO_OUT_HEAD = 2 };
+enum { YOLO_FLAG_RESIDUAL = 1, YOLO_FLAG_NANCHECK = 2 };
+
+/* One fused block: y = [residual +] act(scale[c] * conv(x, w)[c] + shift[c]).
+ * Replaces CNNBlock.forward (model.py:80-86: Conv2d -> BatchNorm2d(eval) -> LeakyReLU/Mish, or
+ * bare Conv2d + bias) and the `x + layer(x)` of ResidualBlock.forward (model.py:115-121).
+ * BN is folded by yolo_bn_fold(); a bare conv passes scale = 1, shift = bias. */
+typedef struct yolo_conv_desc {
+    int32_t n, h, w;        /* input batch, height, width                                  */
+    int32_t cin, cout;      /* logical channel counts                                      */
+    int32_t ksize, stride;  /* 1 or 3 (padding = ksize/2, model.py:201); 1 or 2            */
+    int32_t x_ld, x_off;    /* input channel stride / offset (elements)                    */
+    int32_t y_ld, y_off;    /* output  "   (ignored for YOLO_OUT_HEAD)                     */
+    int32_t r_ld, r_off;    /* residual "  (YOLO_FLAG_RESIDUAL), same spatial size as y    */
+    int32_t act;            /* YOLO_ACT_*                                                  */
+    int32_t out_mode;       /* YOLO_OUT_*                                                  */
+    int32_t dtype;          /* YOLO_F32 (this round); activations and packed weights       */
+    int32_t flags;          /* YOLO_FLAG_*                                                 */
+    int32_t tile;           /* 0 = library heuristic; else forced tile id (tuning/tests)   */
+} yolo_conv_desc;
+
+/* One queued launch for yolo_conv_fwd_batch (pointers as 64-bit integers so the table can be
+ * built once per input shape on the host and replayed every forward). */
+typedef struct yolo_conv_op {
+    yolo_conv_desc d;
+    uint64_t x, w_packed, scale, shift, residual, y;
+} yolo_conv_op;
+
+const char* yolo_last_error(void);
+int yolo_version(void);
+
+/* ---- weights (replaces nothing arithmetic: layout change of nn.Conv2d.weight, OIHW fp32,
+ *      as filled by the Darknet loader model.py:293-305) ---------------------------------- */
+/* elements of the packed buffer: rows padded to 128 output channels, K = k*k*cin_pad padded
+ * to 32, K index = (kh*k + kw)*cin_pad + ci  (channels innermost, matching NHWC gathers). */
+size_t yolo_packed_weight_elems(int cout, int cin, int ksize);
+int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream);
+/* inverse (for gradients / checkpoint export): packed -> OIHW */
+int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream);
+/* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (nn.BatchNorm2d eval,
+ * model.py:61,84). gamma == NULL: scale = 1, shift = beta (bias of a bare conv, model.py:86). */
+int yolo_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                 float* scale, float* shift, int c, void* stream);
+
+/* ---- layout boundary ------------------------------------------------------------------- */
+/* (N,C,H,W) fp32 -> NHWC with c_pad >= C channels (extra channels zero). Sets *nan_flag |= 1 if
+ * any input element is NaN (the `assert torch.sum(torch.isnan(x)) == 0` of model.py:175). */
+int yolo_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int dtype,
+                      int32_t* nan_flag, void* stream);
+int yolo_nhwc_to_nchw(const void* x, float* y, int n, int c, int h, int w, int x_ld, int x_off, int dtype, void* stream);
+
+/* ---- convolution blocks ---------------------------------------------------------------- */
+/* nan_flag: *nan_flag |= 2 when YOLO_FLAG_NANCHECK is set and an output element is NaN
+ * (the per-layer `raise ValueError("Nan in layer")` of model.py:183-184, checked once by host). */
+int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                  const float* shift, const void* residual, void* y, int32_t* nan_flag, void* stream);
+int yolo_conv_fwd_batch(const yolo_conv_op* ops, int n_ops, int32_t* nan_flag, void* stream);
+/* tile id the heuristic would pick (exposed for tests / tuning) and number of tile ids */
+int yolo_conv_pick_tile(const yolo_conv_desc* d);
+int yolo_conv_num_tiles(void);
+
+/* ---- post-processing ------------------------------------------------------------------- */
+/* Replaces cells_to_boxes (utils.py:86-148) for one scale.
+ * pred: (B,3,g,g,5+nc) fp32 addressed through element strides s[5] (so the reference's permuted
+ * view and this library's contiguous head layout both work). is_pred != 0: pred[...,0:2] <-
+ * sigmoid, pred[...,2:4] <- exp * anchors (IN PLACE, like the reference), obj = sigmoid,
+ * cls = first argmax. boxes: (B, n_total, 6) fp32 rows [cx,cy,w,h,obj,cls]; this scale writes
+ * rows box_offset + a*g*g + row*g + col  (n_total, box_offset let three scales share one
+ * buffer in the reference's concatenation order, demo.py:44-51). is_pred == 0: 5+nc must be 6. */
+int yolo_decode(void* pred, const int64_t* strides5, const float* anchors_3x2, int b, int g, int nc,
+                int is_pred, float* boxes, int n_total, int box_offset, void* stream);
+
+/* Replaces non_max_suppression (utils.py:150-191) with calc_iou (utils.py:38-84) inlined,
+ * batched over images. boxes: (B, n, 6) fp32. keep_idx: (B, n) int32, keep_count: (B) int32:
+ * for image b the first keep_count[b] entries are indices into its n input rows, in the
+ * reference's output order (objectness descending, ties in input order). Bit-exact contract:
+ * same kept set and order as the reference for any fp32 input. center != 0 <=> box_format ==
+ * "center"; every other string means (x1,y1,w,h) as is (utils.py:57-67). */
+size_t yolo_nms_workspace_bytes(int b, int n);
+int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_threshold, int center,
+             int32_t* keep_idx, int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_MI355X_H */

@@ -1,0 +1,132 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/yolo_mi355x.h declares; host logic (program builder, loader, state_dict) behaves like
+the reference.  No compute calls (there is no GPU in the build container)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import net as onet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from yolo_for_turbines_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "yolo_mi355x.h")).read()
+    declared = set(re.findall(r"\b(yolo_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"yolo_conv_desc", "yolo_conv_op"}
+    assert declared, "no declarations parsed"
+    lib = built.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(built.EXPORTS) == declared
+    assert lib.yolo_version() >= 100
+
+
+def test_struct_layout_matches_header(built):
+    import ctypes as C
+    assert C.sizeof(built.ConvDesc) == 18 * 4
+    assert C.sizeof(built.ConvOp) == 18 * 4 + 6 * 8
+    assert built.lib().yolo_packed_weight_elems(255, 1024, 1) == 256 * 1024
+    assert built.lib().yolo_packed_weight_elems(32, 3, 3) == 128 * 64
+    assert built.lib().yolo_packed_weight_elems(32, 3, 2) == 0
+
+
+def test_argument_errors_are_reported(built):
+    lib = built.lib()
+    d = built.ConvDesc(n=1, h=8, w=8, cin=5, cout=8, ksize=3, stride=1, x_ld=8, y_ld=8)
+    rc = lib.yolo_conv_pick_tile(d)
+    assert rc < 0 and b"cin" in lib.yolo_last_error()
+    d = built.ConvDesc(n=1, h=8, w=8, cin=32, cout=8, ksize=5, stride=1, x_ld=32, y_ld=8)
+    assert lib.yolo_conv_pick_tile(d) < 0
+    assert lib.yolo_nms_workspace_bytes(2, 1000) > 2 * 1000 * (4 + 32 + 16 * 8)
+
+
+def test_state_dict_keys_and_shapes_match_reference(golden):
+    import yolo_for_turbines_amd as yt
+    m = yt.YOLOv3(num_classes=80)
+    keys = list(m.state_dict().keys())
+    assert keys == list(golden("loader")["state_dict_keys"])
+    spec = dict(onet.state_dict_spec(3, 80))
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(spec[k]), k
+    assert sum(p.numel() for p in m.parameters()) == 61949149
+    assert sum(p.numel() for p in yt.YOLOv3(num_classes=2).parameters()) == 61529119
+    with pytest.raises(ValueError, match="Unsupported activation"):
+        yt.YOLOv3(activation="relu")
+    assert isinstance(m.layers[17], torch.nn.Upsample) and isinstance(m.layers[24], torch.nn.Upsample)
+    assert len(m.layers) == 30
+
+
+@pytest.mark.parametrize("fname,tag", [("yolov3.weights", "full"), ("darknet53.conv.74", "conv74")])
+def test_darknet_loader_offsets_and_cutoff(tmp_path, golden, fname, tag):
+    """Own loader vs the map recorded from the reference loader (same synthetic stream)."""
+    import yolo_for_turbines_amd as yt
+    g = golden("loader")
+    sd = onet.synth_state_dict(21, 3, 80, gain=1.0)
+    stream = onet.darknet_stream(sd, 3, 80)
+    path = tmp_path / fname
+    with open(path, "wb") as f:
+        np.array([0, 2, 0, 32013312, 0], np.int32).tofile(f)
+        stream.tofile(f)
+    assert os.path.getsize(path) == 248007048
+    m = yt.YOLOv3(num_classes=80, weights_path=str(path), freeze=(tag == "conv74"))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_weights()
+    after = m.state_dict()
+    for key, off, cnt, loaded in zip(g[f"{tag}/keys"], g[f"{tag}/offsets"], g[f"{tag}/counts"], g[f"{tag}/loaded"]):
+        key = str(key)
+        if loaded:
+            assert torch.equal(after[key].reshape(-1), torch.from_numpy(stream[off:off + cnt])), key
+        else:
+            assert torch.equal(after[key], before[key]), key
+    assert m.param_idx == 62001757
+    if tag == "conv74":
+        named = dict(m.named_parameters())
+        assert not named["layers.0.conv.weight"].requires_grad
+        assert named["layers.8.layers.5.0.conv.weight"].requires_grad
+    # round trip through the writer
+    out = tmp_path / "out.weights"
+    if tag == "full":
+        m.save_weights(str(out))
+        assert np.array_equal(np.fromfile(out, np.float32, offset=20), stream)
+
+
+def test_program_structure():
+    import yolo_for_turbines_amd as yt
+    from yolo_for_turbines_amd import engine, _lib as L
+    m = yt.YOLOv3(num_classes=80)
+    p = engine.build_network_program(m, 2, 416)
+    assert len(p.ops) == 75 and p.n_pred == 3
+    ups = [op for op in p.ops if op["out_mode"] == L.OUT_UPSAMPLE2X]
+    assert [(op["y"].ld, op["y"].off, op["y"].C) for op in ups] == [(768, 0, 256), (384, 0, 128)]
+    routes = [op for op in p.ops if op["y"] is not None and op["y"].off > 0]
+    assert [(op["y"].ld, op["y"].off, op["y"].C, op["y"].H) for op in routes] == [(384, 128, 256, 52), (768, 256, 512, 26)]
+    heads = [op for op in p.ops if op["out_mode"] == L.OUT_HEAD]
+    assert [op["Ho"] for op in heads] == [13, 26, 52]
+    n_res = sum(1 for op in p.ops if op["flags"] & L.FLAG_RESIDUAL)
+    assert n_res == 23
+    flops = sum(2 * op["Ho"] * op["Wo"] * op["block"].conv.out_channels * op["block"].conv.in_channels * op["k"] ** 2
+                for op in p.ops)
+    assert abs(flops / 1e9 - 65.864) < 0.01
+
+
+def test_cpu_tensor_and_missing_gpu_fail_loudly():
+    import yolo_for_turbines_amd as yt
+    m = yt.YOLOv3(num_classes=2).eval()
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        yt.decode_boxes(torch.zeros(1, 3, 2, 2, 7), torch.ones(3, 2), 2)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        yt.nms_indices(torch.zeros(4, 6), 0.5, 0.5)

@@ -1,0 +1,276 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C-ABI library, against
+(1) the golden vectors generated from the imported reference and (2) the CPU oracle on the
+same seeded inputs.  Tolerances: forward fp32 <= 1e-3 absolute (BASELINE.json north_star);
+decode 2e-6 relative (device expf vs host); NMS kept indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net as onet
+from oracle import postprocess as opp
+from tests import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+FWD_ATOL = 1e-3          # north-star tolerance
+TIGHT_ATOL = 1e-4        # what the fp32 MFMA path actually achieves on these magnitudes
+
+
+@pytest.fixture(scope="module")
+def yt():
+    import yolo_for_turbines_amd as pkg
+    from yolo_for_turbines_amd import _lib
+    _lib.lib()                       # must load: no fallback
+    assert torch.cuda.is_available()
+    return pkg
+
+
+def _block(yt, i, act):
+    cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
+    p = gi.block_params(i, cin, cout, k, bn)
+    blk = yt.CNNBlock(cin, cout, batch_norm_act=bn, activation=act, kernel_size=k, stride=s, padding=1 if k == 3 else 0)
+    blk.conv.weight.data.copy_(torch.from_numpy(p["w"]))
+    if bn:
+        blk.batch_norm.weight.data.copy_(torch.from_numpy(p["gamma"]))
+        blk.batch_norm.bias.data.copy_(torch.from_numpy(p["beta"]))
+        blk.batch_norm.running_mean.data.copy_(torch.from_numpy(p["mean"]))
+        blk.batch_norm.running_var.data.copy_(torch.from_numpy(p["var"]))
+    else:
+        blk.conv.bias.data.copy_(torch.from_numpy(p["bias"]))
+    return blk.cuda().eval(), torch.from_numpy(gi.block_input(i, cin, h))
+
+
+@pytest.mark.parametrize("i", range(len(gi.BLOCK_CONFIGS)))
+def test_conv_block_eval_vs_golden(yt, golden, i):
+    g = golden("blocks")
+    bn = gi.BLOCK_CONFIGS[i][4]
+    for act in (("leaky_relu", "mish") if bn else ("leaky_relu",)):
+        blk, x = _block(yt, i, act)
+        with torch.no_grad():
+            y = blk(x.cuda()).cpu()
+        ref = g[f"cfg{i}/{act}/eval"]
+        np.testing.assert_allclose(y.reshape(-1)[::gi.BLOCK_STRIDE].numpy(), ref, rtol=0, atol=TIGHT_ATOL)
+        s = g[f"cfg{i}/{act}/eval_sums"]
+        assert abs(float(y.double().abs().sum()) - s[1]) <= 1e-5 * s[1]
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("i", [0, 1, 3, 7, 11, 15, 22])
+def test_conv_block_every_tile_vs_oracle(yt, i, tile):
+    """Full-tensor check of each tile shape against the oracle (not only the sampled golden)."""
+    from yolo_for_turbines_amd import engine
+    cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
+    blk, x = _block(yt, i, "leaky_relu")
+    engine._module_state.tile_override = tile
+    try:
+        with torch.no_grad():
+            y = blk(x.cuda()).cpu()
+    finally:
+        engine._module_state.tile_override = None
+    p = gi.block_params(i, cin, cout, k, bn)
+    sd = {"b.conv.weight": torch.from_numpy(p["w"])}
+    if bn:
+        sd.update({"b.batch_norm.weight": torch.from_numpy(p["gamma"]), "b.batch_norm.bias": torch.from_numpy(p["beta"]),
+                   "b.batch_norm.running_mean": torch.from_numpy(p["mean"]), "b.batch_norm.running_var": torch.from_numpy(p["var"])})
+    else:
+        sd["b.conv.bias"] = torch.from_numpy(p["bias"])
+    with torch.no_grad():
+        ref = onet.cnn_block(sd, dict(prefix="b", cin=cin, cout=cout, k=k, stride=s, bn=bn), x, "leaky_relu")
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=0, atol=TIGHT_ATOL)
+
+
+def test_residual_and_head_blocks_vs_golden(yt, golden):
+    g = golden("blocks")
+    rb = yt.ResidualBlock(64, num_blocks=2)
+    rb.load_state_dict({k[len("res64x2/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("res64x2/sd/")})
+    sp = yt.ScalePredictionBlock(128, num_classes=2)
+    sp.load_state_dict({k[len("head128/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("head128/sd/")})
+    with torch.no_grad():
+        yr = rb.cuda().eval()(torch.from_numpy(g["res64x2/x"]).cuda()).cpu().numpy()
+        ys = sp.cuda().eval()(torch.from_numpy(g["head128/x"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(yr, g["res64x2/y"], rtol=0, atol=TIGHT_ATOL)
+    assert ys.shape == g["head128/y"].shape == (2, 3, 6, 6, 7)
+    np.testing.assert_allclose(ys, g["head128/y"], rtol=0, atol=TIGHT_ATOL)
+
+
+def _model(yt, c):
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=c["nc"], activation=c["act"])
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", ["nc80_s96_b2_leaky", "nc2_s128_b1_leaky", "nc80_s96_b1_mish"])
+def test_network_forward_full_vs_golden(yt, golden, name):
+    g = golden("net_fwd")
+    c = gi.NET_CASES[name]
+    m = _model(yt, c)
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+    with torch.no_grad():
+        preds = m(x.cuda())
+    assert len(preds) == 3
+    for i, p in enumerate(preds):
+        ref = g[f"{name}/p{i}"]
+        assert tuple(p.shape) == ref.shape and p.dtype == torch.float32
+        err = np.abs(p.cpu().numpy() - ref).max()
+        assert err <= FWD_ATOL, f"scale {i}: max abs err {err}"
+        assert err <= TIGHT_ATOL, f"scale {i}: fp32 MFMA path should be well inside tolerance, got {err}"
+
+
+@pytest.mark.parametrize("name", ["nc80_s416_b1_leaky", "nc80_s608_b1_leaky"])
+def test_network_forward_sampled_vs_golden(yt, golden, name):
+    g = golden("net_fwd")
+    c = gi.NET_CASES[name]
+    m = _model(yt, c)
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+    with torch.no_grad():
+        preds = m(x.cuda())
+    for i, p in enumerate(preds):
+        flat = p.reshape(-1).cpu()
+        np.testing.assert_allclose(flat[::gi.SAMPLE_STRIDE].numpy(), g[f"{name}/p{i}_sample"], rtol=0, atol=FWD_ATOL)
+        s = g[f"{name}/p{i}_sums"]
+        assert abs(float(flat.double().sum()) - s[0]) <= 2e-5 * s[1]
+        assert abs(float(flat.double().abs().sum()) - s[1]) <= 2e-5 * s[1]
+
+
+def test_network_batch_independence_and_determinism(yt):
+    """Size-independent properties at the bench shape family: each image's output does not
+    depend on its batch neighbours, and two runs are bitwise identical."""
+    c = gi.NET_CASES["nc80_s96_b2_leaky"]
+    m = _model(yt, c)
+    x = onet.synth_input(123, 5, 160).cuda()
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)
+        single = m(x[3:4])
+    for pa, pb, ps in zip(a, b, single):
+        assert torch.equal(pa, pb)
+        assert torch.equal(pa[3:4], ps)
+
+
+def test_nan_guards(yt):
+    c = gi.NET_CASES["nc2_s128_b1_leaky"]
+    m = _model(yt, c)
+    x = onet.synth_input(5, 1, 64).cuda()
+    x[0, 1, 3, 3] = float("nan")
+    with pytest.raises(AssertionError):
+        m(x)
+    x = onet.synth_input(5, 1, 64).cuda()
+    m.layers[4].layers[1][1].batch_norm.bias.data[3] = float("nan")
+    m._engine.invalidate()
+    with pytest.raises(ValueError, match="Nan in layer"):
+        m(x)
+
+
+def test_outputs_are_writable_and_fresh(yt):
+    c = gi.NET_CASES["nc2_s128_b1_leaky"]
+    m = _model(yt, c)
+    x = onet.synth_input(5, 1, 64).cuda()
+    with torch.no_grad():
+        a = m(x)
+        keep = [t.clone() for t in a]
+        a[0][..., 0:2] = 0                    # callers mutate predictions in place (utils.py:106, loss.py:71)
+        b = m(x)
+    for k, t in zip(keep, b):
+        assert torch.equal(k, t)
+
+
+# ------------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("name", list(gi.DECODE_CASES))
+@pytest.mark.parametrize("layout", ["contiguous", "reference_view"])
+def test_decode_vs_golden(yt, golden, name, layout):
+    g = golden("decode")
+    pred, anchors = gi.decode_input(name)
+    grid = gi.DECODE_CASES[name]["g"]
+    p = torch.from_numpy(pred.copy()).cuda()
+    if layout == "reference_view":            # (B,3,D,g,g) memory viewed as (B,3,g,g,D), like model.py:147-148
+        p = p.permute(0, 1, 4, 2, 3).contiguous().permute(0, 1, 3, 4, 2)
+        assert not p.is_contiguous()
+    boxes = yt.decode_boxes(p, torch.from_numpy(anchors), grid)
+    ref = g[f"{name}/boxes"]
+    got = boxes.cpu().numpy()
+    np.testing.assert_allclose(got[..., :5], ref[..., :5], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(got[..., 5], ref[..., 5])
+    np.testing.assert_allclose(p.cpu().numpy(), g[f"{name}/mutated"], rtol=2e-6, atol=1e-7)     # in-place side effect
+    as_list = yt.cells_to_boxes(torch.from_numpy(pred.copy()).cuda(), torch.from_numpy(anchors), grid)
+    assert len(as_list) == pred.shape[0] and len(as_list[0]) == 3 * grid * grid and len(as_list[0][0]) == 6
+
+
+def test_decode_targets_path(yt, golden):
+    g = golden("decode")
+    t = torch.from_numpy(gi.synth_targets(2, 96, 2, gi.TRAIN_CASE["anchors"], 55)[2]).cuda()
+    boxes = yt.decode_boxes(t, torch.zeros(3, 2), 12, is_pred=False)
+    np.testing.assert_array_equal(boxes.cpu().numpy(), g["targets_g12/boxes"])
+
+
+# ---------------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize("name", list(gi.NMS_CASES))
+def test_nms_indices_bit_exact_vs_golden(yt, golden, name):
+    g = golden("nms")
+    boxes, iou_thr, obj_thr, fmt = gi.nms_boxes(name)
+    if len(boxes) == 0:
+        assert yt.non_max_suppression([], iou_thr, obj_thr, fmt) == []
+        return
+    keep, count = yt.nms_indices(torch.from_numpy(boxes).cuda(), iou_thr, obj_thr, fmt)
+    k = int(count)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy().astype(np.int64), g[f"{name}/keep"])
+
+
+def test_nms_batched_ragged_thresholds(yt):
+    """Several images at once, each with a different number of above-threshold boxes, against the
+    C oracle; also the list wrapper returns the reference's rows."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    imgs = []
+    for b in range(7):
+        bx = gi.boxes_clustered(700, 5, 500 + b, n_gt=9, jitter=0.25)
+        bx[:, 4] = rng.random(700).astype(F32) * (0.3 + 0.1 * b)        # image 0: almost nothing passes 0.25
+        imgs.append(bx)
+    batch = np.stack(imgs)
+    keep, count = yt.nms_indices(torch.from_numpy(batch).cuda(), 0.4, 0.25, "center")
+    for b in range(7):
+        want = opp.nms_indices_c(batch[b], 0.4, 0.25, "center")
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+    rows = yt.non_max_suppression(batch[3].tolist(), 0.4, 0.25, "center")
+    np.testing.assert_array_equal(np.asarray(rows, F32), batch[3][opp.nms_indices_c(batch[3], 0.4, 0.25, "center")])
+
+
+def test_nms_full_size_properties(yt):
+    """BASELINE Config-5 size (10,000 post-threshold boxes x 16 images): idempotence (running NMS
+    on the kept boxes keeps all of them, same order), score-sortedness, and exact agreement with
+    the C oracle on every image."""
+    B, N = 16, 10000
+    batch = np.stack([gi.boxes_uniform(N, 80, 9000 + b) if b % 2 == 0 else gi.boxes_clustered(N, 80, 9000 + b, jitter=0.15)
+                      for b in range(B)])
+    t = torch.from_numpy(batch).cuda()
+    keep, count = yt.nms_indices(t, 0.45, 0.5, "center")
+    for b in range(B):
+        k = int(count[b])
+        idx = keep[b, :k].cpu().numpy()
+        np.testing.assert_array_equal(idx, opp.nms_indices_c(batch[b], 0.45, 0.5, "center"))
+        scores = batch[b][idx, 4]
+        assert np.all(scores[:-1] >= scores[1:])
+        again, c2 = yt.nms_indices(t[b, keep[b, :k].long()], 0.45, 0.5, "center")
+        assert int(c2) == k and np.array_equal(again[:k].cpu().numpy(), np.arange(k))
+
+
+def test_detect_pipeline_vs_oracle(yt):
+    """forward -> decode (3 scales, reference concatenation order) -> NMS, against the oracle's
+    decode of the oracle's forward; thresholds chosen so a few hundred boxes survive."""
+    c = gi.NET_CASES["nc80_s96_b2_leaky"]
+    m = _model(yt, c)
+    x = onet.synth_input(77, 3, 128)
+    with torch.no_grad():
+        preds = m(x.cuda())
+    anchors = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+               [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
+    sa = [torch.tensor(a) * p.shape[2] for a, p in zip(anchors, preds)]
+    pc = [p.clone() for p in preds]
+    boxes, keep, count = yt.detect(preds, sa, 0.45, 0.5, "center")
+    ref_boxes = torch.cat([opp.cells_to_boxes(p.cpu(), a, p.shape[2]) for p, a in zip(pc, sa)], dim=1).numpy()
+    got = boxes.cpu().numpy()
+    np.testing.assert_allclose(got[..., :5], ref_boxes[..., :5], rtol=3e-6, atol=1e-7)
+    np.testing.assert_array_equal(got[..., 5], ref_boxes[..., 5])
+    for b in range(3):                        # NMS exactness is defined on the boxes it was given
+        want = opp.nms_indices_c(got[b], 0.45, 0.5, "center")
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)

@@ -1,0 +1,13 @@
+"""yolo_for_turbines_amd — MI355X-native YOLOv3 hot path (forward, box decode, NMS) behind the
+call surface of GabeTsai/YOLO-For-Turbines (`code/model.py`, `code/utils.py`).
+
+The on-disk directory is also reachable as ``yolo-for-turbines_amd`` (symlink; a hyphen is not a
+legal Python identifier). Everything computes in ``libyolo_mi355x.so`` (hand-written gfx950 HIP);
+there is no CPU fallback.
+"""
+from .model import CNNBlock, ResidualBlock, ScalePredictionBlock, YOLOv3, layer_config
+from .utils import (calc_iou, cells_to_boxes, decode_boxes, detect, iou_aligned, nms_indices,
+                    non_max_suppression)
+
+__all__ = ["CNNBlock", "ResidualBlock", "ScalePredictionBlock", "YOLOv3", "layer_config", "calc_iou",
+           "cells_to_boxes", "decode_boxes", "detect", "iou_aligned", "nms_indices", "non_max_suppression"]

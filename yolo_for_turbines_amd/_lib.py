@@ -1,0 +1,94 @@
+"""ctypes binding of ``libyolo_mi355x.so`` (declared in ``include/yolo_mi355x.h``).
+
+There is no CPU fallback: if the HIP library has not been built (``__graft_entry__.build()``
+or ``make -C yolo_for_turbines_amd/csrc``) every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_mi355x.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_MISH = 0, 1, 2
+OUT_NHWC, OUT_UPSAMPLE2X, OUT_HEAD = 0, 1, 2
+FLAG_RESIDUAL, FLAG_NANCHECK = 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "h", "w", "cin", "cout", "ksize", "stride", "x_ld", "x_off", "y_ld", "y_off", "r_ld", "r_off",
+        "act", "out_mode", "dtype", "flags", "tile")]
+
+
+class ConvOp(C.Structure):
+    _fields_ = [("d", ConvDesc)] + [(n, C.c_uint64) for n in ("x", "w_packed", "scale", "shift", "residual", "y")]
+
+
+class YoloLibError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "yolo_last_error": (C.c_char_p, []),
+    "yolo_version": (C.c_int, []),
+    "yolo_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "yolo_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "yolo_unpack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "yolo_bn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_void_p]),
+    "yolo_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "yolo_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "yolo_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "yolo_conv_fwd_batch": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_void_p, C.c_void_p]),
+    "yolo_conv_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "yolo_conv_num_tiles": (C.c_int, []),
+    "yolo_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "yolo_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """The loaded library; raises YoloLibError when it is missing (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YoloLibError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C yolo_for_turbines_amd/csrc`. This package has no CPU fallback.")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:                                  # pragma: no cover
+            raise YoloLibError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().yolo_last_error()
+        raise YoloLibError(f"{what or 'libyolo_mi355x'} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or 0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,185 @@
+// layout.hip — boundary kernels: weight packing, BatchNorm folding, NCHW <-> NHWC.
+// All are HBM-bound byte movers (no reuse): one pass, coalesced on the wider side.
+#include "common.h"
+
+namespace yolo {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// OIHW fp32 (nn.Conv2d.weight as the Darknet loader fills it, model.py:301-305) ->
+// [Cout_pad][K_pad], K index = (kh*ks + kw)*cin_pad + ci. One thread per destination element;
+// the destination is written coalesced, sources are ks*ks-strided gathers of a small tensor.
+__global__ void pack_weights_f32(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int ks,
+                                 int cin_pad, int kpad, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / kpad);
+        const int k = (int)(i - (long long)o * kpad);
+        const int tap = k / cin_pad;
+        const int ci = k - tap * cin_pad;
+        float v = 0.f;
+        if (o < cout && tap < ks * ks && ci < cin) v = w[((size_t)o * cin + ci) * ks * ks + tap];
+        wp[i] = v;
+    }
+}
+
+__global__ void unpack_weights_f32(const float* __restrict__ wp, float* __restrict__ w, int cout, int cin, int ks,
+                                   int cin_pad, int kpad, long long total) {
+    const int kk = ks * ks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % kk);
+        const long long oc = i / kk;
+        const int ci = (int)(oc % cin);
+        const int o = (int)(oc / cin);
+        w[i] = wp[(size_t)o * kpad + tap * cin_pad + ci];
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    if (gamma) {
+        const float s = gamma[i] / sqrtf(var[i] + eps);
+        scale[i] = s;
+        shift[i] = beta[i] - mean[i] * s;
+    } else {
+        scale[i] = 1.f;
+        shift[i] = beta ? beta[i] : 0.f;
+    }
+}
+
+// (N,C,H,W) -> (N,H,W,c_pad). C is tiny (3) at the network input: each thread handles one pixel,
+// reads C planes (coalesced along W) and writes one 16-byte pixel.
+__global__ void nchw_to_nhwc_small(const float* __restrict__ x, float* __restrict__ y, int n, int c, int hw, int c_pad,
+                                   int* nan_flag) {
+    const long long total = (long long)n * hw;
+    bool bad = false;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / hw;
+        const long long pix = i - img * hw;
+        const float* src = x + img * c * hw + pix;
+        float* dst = y + i * c_pad;
+        for (int k = 0; k < c_pad; ++k) {
+            const float v = k < c ? src[(long long)k * hw] : 0.f;
+            bad |= (v != v);
+            dst[k] = v;
+        }
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+// generic tiled transpose for larger C (32x32 tiles through LDS), used by tests / debug taps
+__global__ void nchw_to_nhwc_tiled(const float* __restrict__ x, float* __restrict__ y, int c, int hw, int c_pad, int* nan_flag) {
+    __shared__ float t[32][33];
+    const int img = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    bool bad = false;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int cc = c0 + r, pp = p0 + threadIdx.x;
+        float v = (cc < c && pp < hw) ? x[((size_t)img * c + cc) * hw + pp] : 0.f;
+        bad |= (v != v);
+        t[r][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int pp = p0 + r, cc = c0 + threadIdx.x;
+        if (pp < hw && cc < c_pad) y[((size_t)img * hw + pp) * c_pad + cc] = t[threadIdx.x][r];
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+__global__ void nhwc_to_nchw_tiled(const float* __restrict__ x, float* __restrict__ y, int c, int hw, int x_ld, int x_off) {
+    __shared__ float t[32][33];
+    const int img = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int pp = p0 + r, cc = c0 + threadIdx.x;
+        t[r][threadIdx.x] = (pp < hw && cc < c) ? x[((size_t)img * hw + pp) * x_ld + x_off + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int cc = c0 + r, pp = p0 + threadIdx.x;
+        if (cc < c && pp < hw) y[((size_t)img * c + cc) * hw + pp] = t[threadIdx.x][r];
+    }
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" {
+
+const char* yolo_last_error(void) { return yolo::err_buf(); }
+int yolo_version(void) { return 100; }
+
+size_t yolo_packed_weight_elems(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)coutpad_of(cout) * kpad_of(cin, ksize);
+}
+
+int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream) {
+    if (!w_oihw || !w_packed) return fail(YOLO_ERR_ARG, "pack_weights: null pointer");
+    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "pack_weights: dtype %d", dtype);
+    const long long total = (long long)yolo_packed_weight_elems(cout, cin, ksize);
+    if (!total) return fail(YOLO_ERR_ARG, "pack_weights: bad shape");
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)w_packed, cout, cin,
+                       ksize, cin_pad_of(cin), kpad_of(cin, ksize), total);
+    return check_launch("pack_weights");
+}
+
+int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream) {
+    if (!w_oihw || !w_packed) return fail(YOLO_ERR_ARG, "unpack_weights: null pointer");
+    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "unpack_weights: dtype %d", dtype);
+    if (!yolo_packed_weight_elems(cout, cin, ksize)) return fail(YOLO_ERR_ARG, "unpack_weights: bad shape");
+    const long long total = (long long)cout * cin * ksize * ksize;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(unpack_weights_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w_packed, w_oihw,
+                       cout, cin, ksize, cin_pad_of(cin), kpad_of(cin, ksize), total);
+    return check_launch("unpack_weights");
+}
+
+int yolo_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                 float* shift, int c, void* stream) {
+    if (!scale || !shift || c <= 0) return fail(YOLO_ERR_ARG, "bn_fold: bad arguments");
+    if (gamma && (!beta || !mean || !var)) return fail(YOLO_ERR_ARG, "bn_fold: gamma without beta/mean/var");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps,
+                       scale, shift, c);
+    return check_launch("bn_fold");
+}
+
+int yolo_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int dtype, int32_t* nan_flag,
+                      void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0 || c_pad < c) return fail(YOLO_ERR_ARG, "nchw_to_nhwc: bad arguments");
+    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "nchw_to_nhwc: dtype %d", dtype);
+    const int hw = h * w;
+    if (c_pad <= 8) {
+        const long long total = (long long)n * hw;
+        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(nchw_to_nhwc_small, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (float*)y, n, c, hw, c_pad,
+                           nan_flag);
+    } else {
+        dim3 grid(ceil_div(hw, 32), ceil_div(c_pad, 32), n), block(32, 8);
+        hipLaunchKernelGGL(nchw_to_nhwc_tiled, grid, block, 0, (hipStream_t)stream, x, (float*)y, c, hw, c_pad, nan_flag);
+    }
+    return check_launch("nchw_to_nhwc");
+}
+
+int yolo_nhwc_to_nchw(const void* x, float* y, int n, int c, int h, int w, int x_ld, int x_off, int dtype, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0 || x_ld < c) return fail(YOLO_ERR_ARG, "nhwc_to_nchw: bad arguments");
+    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "nhwc_to_nchw: dtype %d", dtype);
+    const int hw = h * w;
+    dim3 grid(ceil_div(hw, 32), ceil_div(c, 32), n), block(32, 8);
+    hipLaunchKernelGGL(nhwc_to_nchw_tiled, grid, block, 0, (hipStream_t)stream, (const float*)x, y, c, hw, x_ld, x_off);
+    return check_launch("nhwc_to_nchw");
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+"""Host-side engine: turns the module tree into a flat table of fused convolution launches
+over NHWC buffers in HBM and replays it through ``libyolo_mi355x.so``.
+
+Data layout in HBM (fp32 path)
+  * activations: NHWC, one allocation per live tensor, recycled by exact size once dead
+    (liveness pooling);
+  * route / concat tensors (model.py:186-191): ONE allocation of Cu+Cr channels per concat; the
+    route-producing residual stage writes its slice [Cu, Cu+Cr) directly, the 1x1 conv in front
+    of nn.Upsample writes slice [0, Cu) with a 2x-upsampling store — no copy kernels;
+  * weights: packed [Cout_pad][K_pad] (K = (kh,kw,ci)) + folded BatchNorm scale/shift, cached per
+    block and refreshed when the parameter tensors change;
+  * head outputs: (B,3,g,g,5+nc) contiguous, freshly allocated per call (callers mutate them).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+BN_NOTE = "nn.BatchNorm2d eval semantics: scale = gamma / sqrt(var + eps), shift = beta - mean * scale"
+
+
+@dataclass
+class TView:
+    """A (B,H,W,C) slice of an NHWC buffer."""
+    buf: int
+    C: int
+    H: int
+    W: int
+    ld: int
+    off: int
+
+
+def _act_code(block):
+    a = block.activation
+    if a is None:
+        return L.ACT_NONE
+    if isinstance(a, nn.LeakyReLU):
+        if abs(a.negative_slope - 0.1) > 1e-12:
+            raise NotImplementedError("only LeakyReLU(0.1) is built into the epilogue")
+        return L.ACT_LEAKY
+    if isinstance(a, nn.Mish):
+        return L.ACT_MISH
+    raise NotImplementedError(f"activation {type(a).__name__}")
+
+
+def _conv_geom(block):
+    cv = block.conv
+    k, s, p = cv.kernel_size[0], cv.stride[0], cv.padding[0]
+    if cv.kernel_size[0] != cv.kernel_size[1] or cv.stride[0] != cv.stride[1] or k not in (1, 3) or s not in (1, 2) \
+            or p != k // 2 or cv.groups != 1 or cv.dilation != (1, 1):
+        raise NotImplementedError(f"conv config {cv} is outside the YOLOv3 set")
+    return k, s
+
+
+class Program:
+    """Symbolic launch list for one input shape."""
+
+    def __init__(self, batch):
+        self.B = batch
+        self.buf_numel = []          # per symbolic buffer
+        self.ops = []                # dict(block, x, y, res, out_mode, flags, pred)
+        self.n_pred = 0
+
+    def new_buf(self, H, W, ld):
+        self.buf_numel.append(self.B * H * W * ld)
+        return len(self.buf_numel) - 1
+
+    def emit_cnn(self, block, x: TView, res: Optional[TView] = None, dst: Optional[TView] = None,
+                 out_mode=L.OUT_NHWC, nancheck=False, pred=None):
+        k, s = _conv_geom(block)
+        cout = block.conv.out_channels
+        if block.conv.in_channels != x.C:
+            raise ValueError(f"channel mismatch: conv expects {block.conv.in_channels}, tensor has {x.C}")
+        Ho, Wo = (x.H + 2 * (k // 2) - k) // s + 1, (x.W + 2 * (k // 2) - k) // s + 1
+        if out_mode == L.OUT_HEAD:
+            y = None
+        elif dst is not None:
+            y = dst
+        else:
+            y = TView(self.new_buf(Ho, Wo, cout), cout, Ho, Wo, cout, 0)
+        flags = (L.FLAG_RESIDUAL if res is not None else 0) | (L.FLAG_NANCHECK if nancheck else 0)
+        self.ops.append(dict(block=block, x=x, y=y, res=res, out_mode=out_mode, flags=flags, pred=pred,
+                             k=k, s=s, Ho=Ho, Wo=Wo))
+        return y
+
+    def emit_res(self, rb, x: TView, final_dst: Optional[TView] = None, nancheck=True):
+        n = len(rb.layers)
+        for j, seq in enumerate(rb.layers):
+            a, b = seq[0], seq[1]
+            t = self.emit_cnn(a, x)
+            last = j == n - 1
+            x = self.emit_cnn(b, t, res=x if rb.use_residual else None,
+                              dst=final_dst if last else None, nancheck=nancheck and last)
+        return x
+
+    def emit_head(self, sp, x: TView):
+        t = self.emit_cnn(sp.pred_block[0], x)
+        self.emit_cnn(sp.pred_block[1], t, out_mode=L.OUT_HEAD, pred=self.n_pred)
+        self.n_pred += 1
+
+
+def build_network_program(model, B, S):
+    """Walk ``model.layers`` the way the reference forward does (model.py:172-193)."""
+    from .model import CNNBlock, ResidualBlock, ScalePredictionBlock
+    layers = list(model.layers)
+    # pre-pass: pair each route (8-unit residual stage) with the nn.Upsample that pops it (LIFO)
+    c, stack, pair = model.in_channels, [], {}
+    for i, m in enumerate(layers):
+        if isinstance(m, CNNBlock):
+            c = m.conv.out_channels
+        elif isinstance(m, ResidualBlock) and m.num_blocks == 8:
+            stack.append((i, c))
+        elif isinstance(m, nn.Upsample):
+            if not stack:
+                raise ValueError("nn.Upsample without a pending route")
+            ri, cr = stack.pop()
+            pair[ri] = pair[i] = dict(cu=c, cr=cr)
+            c = c + cr
+    prog = Program(B)
+    cin_pad = (model.in_channels + 3) // 4 * 4
+    cur = TView(prog.new_buf(S, S, cin_pad), model.in_channels, S, S, cin_pad, 0)
+    prog.input = cur
+    concat_view = {}                                  # upsample layer index -> TView of the whole concat
+    for i, m in enumerate(layers):
+        if isinstance(m, ScalePredictionBlock):
+            prog.emit_head(m, cur)
+            continue
+        if isinstance(m, CNNBlock):
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if isinstance(nxt, nn.Upsample):
+                info = pair[i + 1]
+                if info["cu"] != m.conv.out_channels:
+                    raise ValueError("unexpected channel count in front of nn.Upsample")
+                cat = info["view"]
+                dst = TView(cat.buf, info["cu"], cat.H, cat.W, cat.ld, 0)
+                prog.emit_cnn(m, cur, dst=dst, out_mode=L.OUT_UPSAMPLE2X, nancheck=True)
+                cur = TView(cat.buf, info["cu"], cat.H // 2, cat.W // 2, cat.ld, 0)   # pre-upsample logical view
+            else:
+                cur = prog.emit_cnn(m, cur, nancheck=True)
+        elif isinstance(m, ResidualBlock):
+            if i in pair:                              # route: write straight into the concat slice
+                info = pair[i]
+                ld = info["cu"] + info["cr"]
+                buf = prog.new_buf(cur.H, cur.W, ld)
+                info["view"] = TView(buf, ld, cur.H, cur.W, ld, 0)
+                dst = TView(buf, info["cr"], cur.H, cur.W, ld, info["cu"])
+                cur = prog.emit_res(m, cur, final_dst=dst)
+            else:
+                cur = prog.emit_res(m, cur)
+        elif isinstance(m, nn.Upsample):
+            cur = pair[i]["view"]                      # upsampled first, route second (model.py:190)
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return prog
+
+
+# ----------------------------------------------------------------------------------------
+class PackedBlock:
+    """Device-side packed weights + folded BN of one CNNBlock."""
+
+    def __init__(self, block, device):
+        cv = block.conv
+        n = L.lib().yolo_packed_weight_elems(cv.out_channels, cv.in_channels, cv.kernel_size[0])
+        if n == 0:
+            raise ValueError("unsupported conv shape")
+        self.w = torch.empty(n, dtype=torch.float32, device=device)
+        self.scale = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
+        self.shift = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
+        self.stamp = None
+
+    @staticmethod
+    def stamp_of(block):
+        ts = [block.conv.weight]
+        if block.batch_norm_act:
+            bn = block.batch_norm
+            ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        else:
+            ts.append(block.conv.bias)
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def refresh(self, block, stream):
+        lib = L.lib()
+        cv = block.conv
+        w = cv.weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
+                                      cv.kernel_size[0], L.F32, stream), "yolo_pack_weights")
+        if block.batch_norm_act:
+            bn = block.batch_norm
+            g, b, m, v = (t.detach().float().contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            L.check(lib.yolo_bn_fold(g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), float(bn.eps),
+                                     self.scale.data_ptr(), self.shift.data_ptr(), cv.out_channels, stream), "yolo_bn_fold")
+        else:
+            b = cv.bias.detach().float().contiguous()
+            L.check(lib.yolo_bn_fold(0, b.data_ptr(), 0, 0, 0.0, self.scale.data_ptr(), self.shift.data_ptr(),
+                                     cv.out_channels, stream), "yolo_bn_fold")
+        self.stamp = self.stamp_of(block)
+
+
+class Plan:
+    """Physical buffers + the ctypes launch table for one Program on one device."""
+
+    def __init__(self, prog: Program, state: "ModelState", device, tile_override=None):
+        self.prog = prog
+        self.device = device
+        B = prog.B
+        n_ops = len(prog.ops)
+        # ---- liveness pooling of activation buffers
+        last_use = [-1] * len(prog.buf_numel)
+        first_def = [n_ops] * len(prog.buf_numel)
+        first_def[prog.input.buf] = -1
+        for i, op in enumerate(prog.ops):
+            for v in (op["x"], op["res"]):
+                if v is not None:
+                    last_use[v.buf] = max(last_use[v.buf], i)
+            if op["y"] is not None:
+                first_def[op["y"].buf] = min(first_def[op["y"].buf], i)
+                last_use[op["y"].buf] = max(last_use[op["y"].buf], i)
+        pool = {}
+        self.phys = [None] * len(prog.buf_numel)
+        self.total_bytes = 0
+
+        def alloc(bid):
+            numel = prog.buf_numel[bid]
+            free = pool.get(numel)
+            if free:
+                self.phys[bid] = free.pop()
+            else:
+                self.phys[bid] = torch.empty(numel, dtype=torch.float32, device=device)
+                self.total_bytes += numel * 4
+        alloc(prog.input.buf)
+        for i in range(n_ops):
+            for bid in range(len(prog.buf_numel)):
+                if first_def[bid] == i and self.phys[bid] is None:
+                    alloc(bid)
+            for bid in range(len(prog.buf_numel)):
+                if last_use[bid] == i and self.phys[bid] is not None and bid != prog.input.buf:
+                    pool.setdefault(prog.buf_numel[bid], []).append(self.phys[bid])
+        # ---- launch table
+        self.table = (L.ConvOp * n_ops)()
+        self.pred_ops = {}
+        self.blocks = []
+        for i, op in enumerate(prog.ops):
+            blk = op["block"]
+            pk = state.packed(blk, device)
+            self.blocks.append(blk)
+            x, y, r = op["x"], op["y"], op["res"]
+            e = self.table[i]
+            d = e.d
+            d.n, d.h, d.w = B, x.H, x.W
+            d.cin, d.cout = blk.conv.in_channels, blk.conv.out_channels
+            d.ksize, d.stride = op["k"], op["s"]
+            d.x_ld, d.x_off = x.ld, x.off
+            if y is not None:
+                d.y_ld, d.y_off = y.ld, y.off
+                e.y = self.phys[y.buf].data_ptr()
+            if r is not None:
+                d.r_ld, d.r_off = r.ld, r.off
+                e.residual = self.phys[r.buf].data_ptr()
+            d.act = _act_code(blk)
+            d.out_mode = op["out_mode"]
+            d.dtype = L.F32
+            d.flags = op["flags"]
+            d.tile = tile_override or 0
+            e.x = self.phys[x.buf].data_ptr()
+            e.w_packed, e.scale, e.shift = pk.w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr()
+            if op["pred"] is not None:
+                self.pred_ops[op["pred"]] = (i, op["Ho"], blk.conv.out_channels // 3)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def launch(self, stream):
+        L.check(L.lib().yolo_conv_fwd_batch(self.table, len(self.table), self.nan_flag.data_ptr(), stream),
+                "yolo_conv_fwd_batch")
+
+
+class ModelState:
+    """Per-model caches (packed weights, plans). Holds no reference to the model so that the
+    model stays picklable / deep-copyable."""
+
+    def __init__(self, model=None):
+        self._packed = {}
+        self._plans = {}
+        self.nan_check = True
+        self.tile_override = None
+
+    def __getstate__(self):
+        return {"nan_check": self.nan_check}
+
+    def __setstate__(self, st):
+        self.__init__()
+        self.nan_check = st.get("nan_check", True)
+
+    def __deepcopy__(self, memo):
+        new = ModelState()
+        new.nan_check = self.nan_check
+        return new
+
+    def invalidate(self, drop_plans=False):
+        for pk in self._packed.values():
+            pk.stamp = None
+        if drop_plans:
+            self._packed.clear()
+            self._plans.clear()
+
+    def packed(self, block, device):
+        key = (id(block), device.index)
+        pk = self._packed.get(key)
+        if pk is None:
+            pk = self._packed[key] = PackedBlock(block, device)
+        return pk
+
+    def refresh_weights(self, blocks, device, stream):
+        for blk in blocks:
+            pk = self.packed(blk, device)
+            if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk):
+                pk.refresh(blk, stream)
+
+    # ------------------------------------------------------------------ inference forward
+    def forward(self, model, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError("expected a (B,C,S,S) tensor")
+        if not x.is_cuda:
+            raise RuntimeError("yolo_for_turbines_amd runs on MI355X only: move the model and the input to the GPU "
+                               "(there is no CPU fallback)")
+        L.lib()                                                   # fail loudly if the HIP library is missing
+        if model.training and torch.is_grad_enabled():
+            from . import train_engine
+            return train_engine.forward_train(self, model, x)
+        B, Cc, H, W = x.shape
+        if Cc != model.in_channels or H != W or H % 32:
+            raise ValueError(f"input must be (B,{model.in_channels},S,S) with S a multiple of 32, got {tuple(x.shape)}")
+        if model.training:
+            raise NotImplementedError("train-mode forward without autograd (batch statistics) is not supported; "
+                                      "call model.eval() for inference")
+        with torch.cuda.device(x.device):
+            stream = L.current_stream()
+            key = (B, H, x.device.index, self.tile_override)
+            plan = self._plans.get(key)
+            if plan is None:
+                prog = build_network_program(model, B, H)
+                plan = self._plans[key] = Plan(prog, self, x.device, self.tile_override)
+            self.refresh_weights(plan.blocks, x.device, stream)
+            xin = x.detach()
+            if xin.dtype != torch.float32 or not xin.is_contiguous():
+                xin = xin.float().contiguous()
+            lib = L.lib()
+            plan.nan_flag.zero_()
+            inp = plan.prog.input
+            L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.phys[inp.buf].data_ptr(), B, Cc, H, W, inp.ld, L.F32,
+                                          plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+            preds = []
+            for k in range(plan.prog.n_pred):
+                i, g, c3 = plan.pred_ops[k]
+                out = torch.empty((B, 3, g, g, c3), dtype=torch.float32, device=x.device)
+                plan.table[i].y = out.data_ptr()
+                preds.append(out)
+            plan.launch(stream)
+            if self.nan_check:
+                flag = int(plan.nan_flag.item())                  # the one host sync of a forward
+                assert not (flag & 1), "NaN in the input tensor"  # model.py:175
+                if flag & 2:
+                    raise ValueError("Nan in layer")              # model.py:183-184
+        return preds
+
+
+# ------------------------------------------------------------------ stand-alone sub-modules
+_module_state = ModelState()
+
+
+def run_module_nchw(module, x):
+    """Run a CNNBlock / ResidualBlock / ScalePredictionBlock by itself on an NCHW tensor
+    (the reference's block-level tests call them directly: model_tests.py:16-45)."""
+    from .model import CNNBlock, ResidualBlock, ScalePredictionBlock
+    if not x.is_cuda:
+        raise RuntimeError("yolo_for_turbines_amd runs on MI355X only (no CPU fallback)")
+    if module.training and any(isinstance(m, nn.BatchNorm2d) for m in module.modules()) and torch.is_grad_enabled():
+        from . import train_engine
+        return train_engine.run_module_train(module, x)
+    lib = L.lib()
+    B, Cc, H, W = x.shape
+    with torch.cuda.device(x.device):
+        stream = L.current_stream()
+        prog = Program(B)
+        cpad = (Cc + 3) // 4 * 4
+        cur = TView(prog.new_buf(H, W, cpad), Cc, H, W, cpad, 0)
+        prog.input = cur
+        if isinstance(module, CNNBlock):
+            out = prog.emit_cnn(module, cur)
+        elif isinstance(module, ResidualBlock):
+            out = prog.emit_res(module, cur, nancheck=False)
+        elif isinstance(module, ScalePredictionBlock):
+            prog.emit_head(module, cur)
+            out = None
+        else:
+            raise NotImplementedError(type(module).__name__)
+        plan = Plan(prog, _module_state, x.device, _module_state.tile_override)
+        _module_state.refresh_weights(plan.blocks, x.device, stream)
+        xin = x.detach().float().contiguous()
+        L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.phys[cur.buf].data_ptr(), B, Cc, H, W, cpad, L.F32,
+                                      plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+        result = None
+        if out is None:
+            i, g, c3 = plan.pred_ops[0]
+            result = torch.empty((B, 3, g, g, c3), dtype=torch.float32, device=x.device)
+            plan.table[i].y = result.data_ptr()
+        plan.launch(stream)
+        if out is not None:
+            result = torch.empty((B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
+            L.check(lib.yolo_nhwc_to_nchw(plan.phys[out.buf].data_ptr(), result.data_ptr(), B, out.C, out.H, out.W,
+                                          out.ld, out.off, L.F32, stream), "yolo_nhwc_to_nchw")
+        torch.cuda.current_stream().synchronize()      # plan buffers die with this call
+        _module_state._packed.clear()
+    return result

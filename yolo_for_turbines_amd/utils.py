@@ -1,0 +1,150 @@
+"""Drop-in mirror of the reference's post-processing functions
+(`/root/reference/code/utils.py:22-191`) on top of the HIP kernels.
+
+Two levels:
+  * list-returning wrappers with the reference's names and signatures (``cells_to_boxes``,
+    ``non_max_suppression``, ``calc_iou``, ``iou_aligned``) so ``demo.predict`` /
+    ``get_eval_boxes`` keep working unchanged (they pay the reference's ``.tolist()`` cost);
+  * device-resident entries (``decode_boxes``, ``nms_indices``, ``detect``) that keep every
+    intermediate in HBM and return tensors — this is the path that is benchmarked.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+__all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
+           "detect"]
+
+
+# -------------------------------------------------------------------------------- IoU
+def iou_aligned(box1, box2):
+    """Width/height IoU of centre-aligned boxes (utils.py:22-36). Elementwise torch ops; not on
+    the accelerated path (used by the dataset's anchor matching)."""
+    inter = torch.min(box1[..., 0], box2[..., 0]) * torch.min(box1[..., 1], box2[..., 1])
+    return inter / (box1[..., 0] * box1[..., 1] + box2[..., 0] * box2[..., 1] - inter)
+
+
+def calc_iou(boxes1, boxes2, box_format="center"):
+    """IoU of cxcywh ("center") or x1y1wh (anything else) boxes, +1e-6 in the denominator
+    (utils.py:38-84). Elementwise torch ops on whatever device the inputs live on: it is the
+    objectness-loss helper (loss.py:64); inside NMS the same arithmetic runs in the HIP kernel."""
+    if boxes1.dim() == 1:
+        boxes1 = boxes1.unsqueeze(0)
+    if boxes2.dim() == 1:
+        boxes2 = boxes2.unsqueeze(0)
+    if box_format == "center":
+        x1, y1 = boxes1[..., 0] - boxes1[..., 2] / 2, boxes1[..., 1] - boxes1[..., 3] / 2
+        x2, y2 = boxes2[..., 0] - boxes2[..., 2] / 2, boxes2[..., 1] - boxes2[..., 3] / 2
+    else:
+        x1, y1, x2, y2 = boxes1[..., 0], boxes1[..., 1], boxes2[..., 0], boxes2[..., 1]
+    w1, h1, w2, h2 = boxes1[..., 2], boxes1[..., 3], boxes2[..., 2], boxes2[..., 3]
+    iw = torch.clamp(torch.min(x1 + w1, x2 + w2) - torch.max(x1, x2), min=0)
+    ih = torch.clamp(torch.min(y1 + h1, y2 + h2) - torch.max(y1, y2), min=0)
+    inter = iw * ih
+    return inter / (w1 * h1 + w2 * h2 - inter + 1e-6)
+
+
+# ------------------------------------------------------------------------------ decode
+def decode_boxes(predictions, anchors, grid_size=None, is_pred=True, out=None, box_offset=0):
+    """Device decode of one scale: (B,3,g,g,5+nc) -> (B, 3*g*g, 6) fp32 tensor
+    [cx,cy,w,h,obj,cls] normalised to [0,1]; mutates ``predictions[...,0:4]`` in place when
+    ``is_pred`` exactly like the reference (utils.py:106-110). ``out`` / ``box_offset`` let
+    several scales share one (B, N_total, 6) buffer."""
+    if not predictions.is_cuda:
+        raise RuntimeError("decode_boxes runs on MI355X only (no CPU fallback)")
+    if predictions.dtype != torch.float32:
+        raise NotImplementedError("decode_boxes: fp32 predictions only in this build")
+    B, A, g, g2, D = predictions.shape
+    if A != 3 or g != g2 or (grid_size is not None and int(grid_size) != g):
+        raise ValueError(f"bad prediction shape {tuple(predictions.shape)} for grid {grid_size}")
+    n = 3 * g * g
+    if out is None:
+        out = torch.empty((B, n, 6), dtype=torch.float32, device=predictions.device)
+        box_offset = 0
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != B or out.shape[2] != 6:
+        raise ValueError("out must be a contiguous (B, N, 6) fp32 tensor")
+    anc = torch.as_tensor(anchors, dtype=torch.float32, device=predictions.device).reshape(3, 2).contiguous() \
+        if is_pred else None
+    strides = (C.c_int64 * 5)(*predictions.stride())
+    with torch.cuda.device(predictions.device):
+        L.check(L.lib().yolo_decode(predictions.data_ptr(), strides, L.ptr(anc), B, g, D - 5, int(bool(is_pred)),
+                                    out.data_ptr(), out.shape[1], int(box_offset), L.current_stream()), "yolo_decode")
+    return out
+
+
+def cells_to_boxes(predictions, anchors, grid_size, is_pred=True):
+    """Reference signature (utils.py:86-148): returns ``list[B][3*g*g][6]``."""
+    return decode_boxes(predictions, anchors, grid_size, is_pred).tolist()
+
+
+# --------------------------------------------------------------------------------- NMS
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = device.index
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def nms_indices(boxes, iou_threshold, obj_threshold, box_format="corners"):
+    """Batched device NMS. ``boxes``: (B, N, 6) or (N, 6) fp32 CUDA tensor of
+    [x,y,w,h,obj,cls]. Returns (keep_idx (B,N) int32, keep_count (B,) int32): for image b the
+    first keep_count[b] entries index its input rows in the reference's output order."""
+    if not boxes.is_cuda:
+        raise RuntimeError("nms_indices runs on MI355X only (no CPU fallback)")
+    single = boxes.dim() == 2
+    if single:
+        boxes = boxes.unsqueeze(0)
+    if boxes.dim() != 3 or boxes.shape[-1] != 6:
+        raise ValueError("boxes must be (B, N, 6)")
+    boxes = boxes.float().contiguous()
+    B, N, _ = boxes.shape
+    keep = torch.empty((B, max(N, 1)), dtype=torch.int32, device=boxes.device)
+    count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
+    lib = L.lib()
+    with torch.cuda.device(boxes.device):
+        nbytes = lib.yolo_nms_workspace_bytes(B, N)
+        ws = _workspace(max(nbytes, 256), boxes.device)
+        L.check(lib.yolo_nms(boxes.data_ptr(), B, N, float(iou_threshold), float(obj_threshold),
+                             int(box_format == "center"), keep.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                             L.current_stream()), "yolo_nms")
+    if single:
+        return keep[0], count[0]
+    return keep, count
+
+
+def non_max_suppression(boxes, iou_threshold, obj_threshold, box_format="corners"):
+    """Reference signature (utils.py:150-191): list of [x,y,w,h,obj,cls] lists in, kept boxes
+    out (objectness-descending). The list is shipped to the GPU, suppressed there, and the kept
+    rows are returned as Python lists of the same fp32 values the reference would produce."""
+    if len(boxes) == 0:
+        return []
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor(boxes, dtype=torch.float32).reshape(-1, 6).to(dev)
+    keep, count = nms_indices(t, iou_threshold, obj_threshold, box_format)
+    k = int(count.item())
+    return t[keep[:k].long()].tolist() if k else []
+
+
+def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, box_format="center"):
+    """Fused post-processing of a forward pass (the sequence of demo.py:44-55 /
+    utils.py:300-321, all images at once, nothing leaves HBM):
+    decode three scales into one (B, N, 6) buffer in the reference's concatenation order
+    (scale 0, 1, 2), then per-image NMS. Returns (boxes (B,N,6), keep_idx (B,N), keep_count (B,))."""
+    B = predictions[0].shape[0]
+    n_per = [3 * p.shape[2] * p.shape[2] for p in predictions]
+    total = sum(n_per)
+    boxes = torch.empty((B, total, 6), dtype=torch.float32, device=predictions[0].device)
+    off = 0
+    for p, a, n in zip(predictions, scaled_anchors, n_per):
+        decode_boxes(p, a, p.shape[2], True, out=boxes, box_offset=off)
+        off += n
+    keep, count = nms_indices(boxes, iou_threshold, obj_threshold, box_format)
+    return boxes, keep, count
