@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — images/s of the YOLOv3 forward hot path on MI355X (BASELINE.json metric).
+
+Workload at N=1 = BASELINE.json configs[1]: batch 32, 416x416, fp32 inference, 80-class COCO
+head, one MI355X; synthetic input already resident in HBM, seeded random weights of the exact
+architecture (no pretrained file exists offline).  One "step" = one forward of the batch through
+the drop-in ``YOLOv3`` module: NCHW->NHWC boundary kernel, 75 fused convolution launches, the NaN
+sticky-flag check (one host sync, as the reference's forward does 27).  N>1: one process per GPU
+(torchrun), every rank runs the same per-GPU batch on its own images (weak scaling, images are
+independent: no data-path collective), barrier + max-over-ranks timing.
+
+Prints ONE JSON line. Extra objects:
+  roofline      the conv kernel family (v_mfma_f32_32x32x2_f32 implicit GEMM): algorithmic conv
+                FLOPs of one step / sum of the per-launch durations measured with HIP events on the
+                launch stream, vs the 157.3 TFLOP/s dense f32 matrix peak.
+  cpu_baseline  the oracle (CPU restatement of the reference, torch CPU ops) timed on this host on
+                a bounded sample of the same workload (rank 0, N=1 only).
+  nms           secondary metric of BASELINE.json: boxes/s of batched NMS at 10,000 post-threshold
+                boxes per image (device path vs the list-based CPU port).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, capped at the
+    GPU box's share (16 per GPU) — os.cpu_count() reports the whole host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-input MFMA peak
+GFLOP_PER_IMAGE_416_NC80 = 65.864     # BASELINE.md §2 (75 convs, 2*Ho*Wo*Cout*Cin*k^2)
+
+
+def seeded_model(yt, nc, device, seed=0, gain=0.8):
+    """Random weights of the exact architecture: W ~ N(0, gain/fan_in), non-trivial BN stats."""
+    m = yt.YOLOv3(num_classes=nc)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                fan_in = mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1]
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * (gain / fan_in) ** 0.5)
+                if mod.bias is not None:
+                    mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+            elif isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+                mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+    return m.to(device).eval()
+
+
+def conv_flops(plan):
+    """Algorithmic FLOPs of every launch in the plan (one step), per launch."""
+    out = []
+    for op in plan.prog.ops:
+        cv = op["block"].conv
+        out.append(2.0 * plan.prog.B * op["Ho"] * op["Wo"] * cv.out_channels * cv.in_channels * op["k"] ** 2)
+    return out
+
+
+def per_launch_times(plan, reps):
+    """Per-launch durations (ms) with HIP events on the launch stream, `reps` passes."""
+    from yolo_for_turbines_amd import _lib as L
+    lib = L.lib()
+    stream = L.current_stream()
+    n = len(plan.table)
+    acc = np.zeros(n)
+    alive = []                                   # fresh head outputs (the table's old ones belong to a past call)
+    for k in range(plan.prog.n_pred):
+        i, g, c3 = plan.pred_ops[k]
+        alive.append(torch.empty((plan.prog.B, 3, g, g, c3), dtype=torch.float32, device=plan.device))
+        plan.table[i].y = alive[-1].data_ptr()
+    for _ in range(reps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i in range(n):
+            e = plan.table[i]
+            L.check(lib.yolo_conv_fwd(e.d, e.x, e.w_packed, e.scale, e.shift, e.residual, e.y, plan.nan_flag.data_ptr(),
+                                      stream), "yolo_conv_fwd")
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
+    return acc / reps
+
+
+def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
+    from tests import golden_inputs as gi       # seeded box generators (data only)
+    batch = np.stack([gi.boxes_uniform(n, nc, 1000 + b) for b in range(images)])
+    t = torch.from_numpy(batch).to(device)
+    yt.nms_indices(t, 0.45, 0.5, "center")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        keep, count = yt.nms_indices(t, 0.45, 0.5, "center")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(boxes_per_s=images * n / dt, images=images, boxes_per_image=n, classes=nc, ms_per_batch=dt * 1e3,
+                kept_mean=float(count.float().mean())), batch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (tuning)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import yolo_for_turbines_amd as yt
+    model = seeded_model(yt, args.classes, device)
+    if args.tile:
+        model._engine.tile_override = args.tile
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.rand((args.batch, 3, args.size, args.size), generator=g).to(device)   # resident in HBM before timing
+
+    log(f"model + input ready on {device}")
+    with torch.no_grad():
+        for i in range(args.warmup):
+            model(x)
+            torch.cuda.synchronize()
+            log(f"warmup {i} done")
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(x)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    images = args.batch * world * args.steps
+    value = images / elapsed
+    gflop_img = GFLOP_PER_IMAGE_416_NC80 if (args.size == 416 and args.classes == 80) else None
+
+    result = {
+        "metric": "images/sec at 416x416 (fwd)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch {args.batch}/GPU {args.size}x{args.size} fp32 inference, "
+                               f"{args.classes}-class head, YOLOv3 forward (75 fused conv launches)",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": args.size,
+                   "num_classes": args.classes, "parallelism": f"image-sharded x{world} (no collective)"},
+    }
+
+    if rank == 0:
+        # ------------------------------------------------------------ roofline (dominant kernel)
+        plan = next(iter(model._engine._plans.values()))
+        flops = conv_flops(plan)
+        with torch.no_grad():
+            times_ms = per_launch_times(plan, reps=max(1, min(args.steps, 5)))
+        log("per-launch event timing done")
+        is3 = np.array([op["k"] == 3 for op in plan.prog.ops])
+        f3, t3 = float(np.sum(np.array(flops)[is3])), float(np.sum(times_ms[is3])) * 1e-3
+        fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
+        ach = f3 / t3 / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)",
+            "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
+            "algorithmic_gflop_per_step": round(f3 / 1e9, 2),
+            "all_conv_launches": {"achieved": round(fall / tall / 1e12, 2), "launches_per_step": len(flops),
+                                  "sum_kernel_ms": round(tall * 1e3, 3), "gflop_per_step": round(fall / 1e9, 2)},
+            "whole_step_tflops": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
+        }
+        # ------------------------------------------------------------------ NMS secondary metric
+        nms_batch = None
+        if not args.no_nms:
+            result["nms"], nms_batch = nms_bench(yt, device)
+            log("nms bench done")
+        # -------------------------------------------------------------------------- CPU baseline
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import net as onet
+            from oracle import postprocess as opp
+            torch.set_num_threads(host_cores())
+            log(f"cpu baseline on {torch.get_num_threads()} threads")
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            xb = x[:8].cpu()
+            with torch.no_grad():
+                onet.forward(sd, xb[:1], args.classes)          # first-touch
+                t0 = time.perf_counter()
+                reps = 0
+                while reps < 2 or (time.perf_counter() - t0 < 10 and reps < 8):
+                    onet.forward(sd, xb, args.classes)
+                    reps += 1
+                dt = time.perf_counter() - t0
+            log("cpu forward baseline done")
+            result["cpu_baseline"] = {
+                "value": round(8 * reps / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{reps} x batch 8 of the same {args.size}x{args.size} fp32 forward (oracle/net.py, torch CPU ops)"}
+            if nms_batch is not None:
+                t0 = time.perf_counter()
+                opp.nms_list(nms_batch[0].tolist(), 0.45, 0.5, "center")
+                dt = time.perf_counter() - t0
+                result["nms"]["cpu_port_boxes_per_s"] = round(nms_batch.shape[1] / dt, 1)
+                result["nms"]["cpu_port_sample"] = "1 image x 10,000 boxes, list-based port (oracle/postprocess.py:nms_list)"
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
