@@ -72,8 +72,11 @@ int yolo_version(void);
 
 /* ---- weights (replaces nothing arithmetic: layout change of nn.Conv2d.weight, OIHW fp32,
  *      as filled by the Darknet loader model.py:293-305) ---------------------------------- */
-/* elements of the packed buffer: rows padded to 128 output channels, K = k*k*cin_pad padded
- * to 32, K index = (kh*k + kw)*cin_pad + ci  (channels innermost, matching NHWC gathers). */
+/* elements of the packed buffer. It holds (1) the row-major matrix [cout_pad128][K_pad32],
+ * K index = (kh*k + kw)*cin_pad + ci (channels innermost, matching NHWC gathers), used by the
+ * register-staged kernel, and, when cin % 32 == 0, (2) a copy in MFMA-fragment order
+ * [cout_pad128/32][cin/32][k*k][4][64 lanes][4] streamed straight into registers by the
+ * stride-1 patch kernel. */
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize);
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream);
 /* inverse (for gradients / checkpoint export): packed -> OIHW */

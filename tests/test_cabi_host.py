@@ -37,7 +37,7 @@ def test_struct_layout_matches_header(built):
     import ctypes as C
     assert C.sizeof(built.ConvDesc) == 18 * 4
     assert C.sizeof(built.ConvOp) == 18 * 4 + 6 * 8
-    assert built.lib().yolo_packed_weight_elems(255, 1024, 1) == 256 * 1024
+    assert built.lib().yolo_packed_weight_elems(255, 1024, 1) == 2 * 256 * 1024      # row-major + fragment-order copy
     assert built.lib().yolo_packed_weight_elems(32, 3, 3) == 128 * 64
     assert built.lib().yolo_packed_weight_elems(32, 3, 2) == 0
 

@@ -54,8 +54,8 @@ def test_conv_block_eval_vs_golden(yt, golden, i):
         assert abs(float(y.double().abs().sum()) - s[1]) <= 1e-5 * s[1]
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
-@pytest.mark.parametrize("i", [0, 1, 3, 7, 11, 15, 22])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("i", [0, 1, 2, 3, 7, 9, 10, 11, 15, 16, 18, 21, 22, 24])
 def test_conv_block_every_tile_vs_oracle(yt, i, tile):
     """Full-tensor check of each tile shape against the oracle (not only the sampled golden)."""
     from yolo_for_turbines_amd import engine
@@ -63,6 +63,11 @@ def test_conv_block_every_tile_vs_oracle(yt, i, tile):
     blk, x = _block(yt, i, "leaky_relu")
     engine._module_state.tile_override = tile
     try:
+        if tile >= 5 and (s != 1 or cin % 32):          # patch kernel: stride 1, cin % 32 == 0 only
+            from yolo_for_turbines_amd._lib import YoloLibError
+            with pytest.raises(YoloLibError, match="stride 1"):
+                blk(x.cuda())
+            return
         with torch.no_grad():
             y = blk(x.cuda()).cpu()
     finally:

@@ -25,4 +25,14 @@ inline int cin_pad_of(int cin) { return round_up(cin, 4); }
 inline int kpad_of(int cin, int ks) { return round_up(ks * ks * cin_pad_of(cin), 32); }
 inline int coutpad_of(int cout) { return round_up(cout, 128); }
 
+
+// conv_f32_v2.hip ("patch + fragment stream" kernel, stride 1, cin % 32 == 0)
+bool v2_eligible(const yolo_conv_desc* d);
+size_t v2_frag_elems(int cout, int cin, int ks);
+int v2_pack(const float* w_oihw, float* wf, int cout, int cin, int ks, hipStream_t s);
+int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
+                   const void* residual, void* y, int32_t* nan_flag, int bn, hipStream_t s);
+// offset (elements) of the fragment-order copy inside a packed weight buffer
+inline size_t v0_packed_elems(int cout, int cin, int ks) { return (size_t)coutpad_of(cout) * kpad_of(cin, ks); }
+
 }  // namespace yolo

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 // ------------------------------------------------------------------------------ host side
 struct TileCfg { int bm, bn; };
 static const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
-constexpr int kNumTiles = 4;
+constexpr int kNumTiles = 6;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }
 
@@ -241,20 +241,12 @@ static int launch_tile(const ConvArgs& a, bool smallc, hipStream_t s) {
     return check_launch("conv_igemm_f32");
 }
 
-// Estimated cost of a tile choice: rounds of 256 CUs x MFMA work per block, with a mild
-// penalty for small tiles (more LDS/L2 traffic and epilogue per FLOP). Tuned on MI355X.
-static int pick_tile(int M, int cout) {
-    static const double penalty[] = {0, 1.00, 1.04, 1.04, 1.10};
-    int best = 1;
-    double best_cost = 1e300;
-    for (int t = 1; t <= kNumTiles; ++t) {
-        const int bm = kTiles[t].bm, bn = kTiles[t].bn;
-        const long blocks = (long)ceil_div(M, bm) * ceil_div(cout, bn);
-        const long rounds = (blocks + 255) / 256;
-        const double cost = (double)rounds * bm * bn * penalty[t];
-        if (cost < best_cost) { best_cost = cost; best = t; }
-    }
-    return best;
+// Measured on MI355X (tools/conv_bench.py, batch 32). The register-staged kernel of this file is
+// latency-bound, so among its tiles 64x64 (4+ resident blocks per CU) wins on every YOLOv3 shape;
+// stride-1 layers with cin % 32 == 0 go to the patch/fragment-stream kernel (ids 5, 6).
+static int pick_tile(const yolo_conv_desc* d) {
+    if (v2_eligible(d)) return d->cout > 64 ? 6 : 5;
+    return 4;
 }
 
 static int validate(const yolo_conv_desc* d) {
@@ -296,7 +288,12 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
     a.tiles_n = 0;
     const bool smallc = a.Cin == 4;
-    const int t = d->tile ? d->tile : pick_tile(a.M, a.Cout);
+    const int t = d->tile ? d->tile : pick_tile(d);
+    if (t >= 5) {
+        if (!v2_eligible(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile %d needs stride 1 and cin %% 32 == 0", t);
+        const float* wf = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize);
+        return conv_v2_launch(d, x, wf, scale, shift, residual, y, nan_flag, t == 6 ? 128 : 64, s);
+    }
     switch (t) {
         case 1: return launch_tile<128, 128>(a, smallc, s);
         case 2: return launch_tile<128, 64>(a, smallc, s);
@@ -314,9 +311,7 @@ int yolo_conv_num_tiles(void) { return yolo::kNumTiles; }
 int yolo_conv_pick_tile(const yolo_conv_desc* d) {
     int rc = yolo::validate(d);
     if (rc) return rc;
-    const int pad = d->ksize / 2;
-    const int ho = (d->h + 2 * pad - d->ksize) / d->stride + 1, wo = (d->w + 2 * pad - d->ksize) / d->stride + 1;
-    return yolo::pick_tile(d->n * ho * wo, d->cout);
+    return yolo::pick_tile(d);
 }
 
 int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,

@@ -1,0 +1,356 @@
+// conv_f32_v2.hip — stride-1 3x3 / 1x1 fp32 convolution, "patch + fragment stream" structure.
+//
+// Same arithmetic and epilogues as conv_f32.hip (reference: CNNBlock.forward code/model.py:80-86,
+// ResidualBlock skip :115-121, upsample+concat :189-191, head permute :145-148); different data
+// movement, designed from the MI355X measurements of the v0 kernel (latency-bound at ~50-67 % of
+// the f32 MFMA peak because every K step re-gathered activations from L2/HBM behind a barrier):
+//
+//  A (activations)  one block owns a spatial tile of TH x TW output pixels (TH*TW <= 128 MFMA rows;
+//      rows are GLOBAL output rows n*H+h, so a tile may straddle images and no H-divisibility is
+//      needed). Per 32-channel chunk it stages the (TH+2 [+2 per image crossed]) x (TW+2) input
+//      patch — halo and zero padding included — in LDS ONCE and all 9 taps read it at shifted
+//      pixel addresses: 9x fewer activation loads, one barrier per 9 K steps instead of one per step.
+//  B (weights)      never touches LDS: yolo_pack_weights also emits a copy in MFMA-fragment order
+//      [n_tile32][kstep][sub-step][lane][4], so a wave's B operand for 8 k-values x 32 couts is one
+//      fully contiguous 1 KiB global_load_dwordx4 wave-instruction, prefetched one K step (64 MFMAs)
+//      ahead into a second register set. Weights are L2/MALL resident (<= 18.9 MB per layer).
+//  MFMA             v_mfma_f32_32x32x2_f32, wave tile 64 x (BN/2), 2x2 waves, block 128 x BN.
+#include "common.h"
+
+namespace yolo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int V2_LD = 36;          // floats per patch pixel in LDS (32 + 4 pad)
+constexpr int V2_NI = 8;           // patch pixels staged per 8-lane group -> patch <= 256 pixels
+constexpr int V2_PATCH_CAP = 32 * V2_NI;
+
+struct Conv2Args {
+    const float* x;
+    const float* wf;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int* nan_flag;
+    int H, W, rows_total;      // tiling view of the output (1x1: H = 1, W = M, rows_total = 1)
+    int Cin, Cout;
+    int x_ld, x_off, y_ld, y_off, r_ld, r_off;
+    int TH, TW, PC, patch_cap;  // tile rows/cols, patch columns, LDS pixels per buffer
+    int tiles_w, tiles_n, nblocks;
+    int KT, nchunks;
+    int act, out_mode, flags, nc5;
+    int Ho, Wo;                 // real output dims (upsample / head addressing)
+};
+
+__device__ __forceinline__ float act_apply2(float v, int act) {
+    if (act == YOLO_ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
+    if (act == YOLO_ACT_MISH) {
+        float sp = v > 20.f ? v : log1pf(__expf(v));
+        return v * tanhf(sp);
+    }
+    return v;
+}
+
+template <int KS, int TN>
+struct V2Ctx {
+    const float* wfrag[TN];     // per n-tile fragment stream base (+ lane*4)
+    int a_off[2];               // LDS float offset of this lane's pixel for m-tile 0/1 (+4h)
+    int pix[V2_NI];             // global pixel index of staged patch pixels (-1: zero)
+    int KT;
+};
+
+// one K step: 32 channels of one tap = 4 sub-steps of 8 k-values. B fragments live in a 4-slot
+// register ring indexed by sub-step; the load for sub-step i+3 is issued at the top of sub-step i
+// into the slot consumed at sub-step i-1 (prefetch distance 3 sub-steps = 48 MFMAs per wave).
+template <int KS, int TN>
+__device__ __forceinline__ void v2_kstep(const Conv2Args& p, const V2Ctx<KS, TN>& c, int kt, float* patch,
+                                         f32x4 (&ring)[4][TN], f32x4 (&stage)[V2_NI], f32x16 (&acc)[2][TN], int tid) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PF_TAP = TAPS > 3 ? TAPS - 3 : 0;      // when to fetch the next chunk's patch
+    const int chunk = kt / TAPS, tap = kt - chunk * TAPS;
+    const bool more = chunk + 1 < p.nchunks;
+    if (tap == PF_TAP && more) {
+        const int coff = p.x_off + (chunk + 1) * 32 + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < V2_NI; ++i) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            stage[i] = c.pix[i] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + (size_t)c.pix[i] * p.x_ld + coff) : z;
+        }
+    }
+    const int kh = tap / KS, kw = tap - kh * KS;
+    const float* Ab = patch + (chunk & 1) * (p.patch_cap * V2_LD) + (kh * p.PC + kw) * V2_LD;
+    const int last_sub = c.KT * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int ahead = kt * 4 + s + 3;
+        if (ahead < last_sub) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                ring[(s + 3) & 3][j] = *reinterpret_cast<const f32x4*>(c.wfrag[j] + (size_t)ahead * 256);
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + c.a_off[0] + s * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + c.a_off[1] + s * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], ring[s][j][e], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], ring[s][j][e], acc[1][j], 0, 0, 0);
+            }
+    }
+    if (tap == TAPS - 1 && more) {
+        float* dst = patch + ((chunk + 1) & 1) * (p.patch_cap * V2_LD) + (tid >> 3) * V2_LD + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < V2_NI; ++i)
+            if ((tid >> 3) + 32 * i < p.patch_cap) *reinterpret_cast<f32x4*>(dst + 32 * i * V2_LD) = stage[i];
+        __syncthreads();
+    }
+}
+
+template <int KS, int BN>
+__global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
+    constexpr int TN = BN / 64;          // 32-wide n tiles per wave (wave tile 64 x BN/2)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* patch = reinterpret_cast<float*>(smem_raw);      // [2][patch_cap][V2_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fh = lane >> 5, frow = lane & 31;
+
+    // XCD-aware, bijective block remap: blocks sharing a spatial tile (n tiles) and neighbouring
+    // tiles land on the same XCD / L2 (speed only; any placement is correct).
+    int bid = blockIdx.x;
+    {
+        const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int n_tile = bid % p.tiles_n;
+    const int sp = bid / p.tiles_n;
+    const int w_tile = sp % p.tiles_w;
+    const int r_tile = sp / p.tiles_w;
+    const int g0 = r_tile * p.TH, c0 = w_tile * p.TW;
+    const int g_last = (g0 + p.TH < p.rows_total ? g0 + p.TH : p.rows_total) - 1;
+    auto vrow = [&](int g) { return KS == 3 ? g + 2 * (g / p.H) : g; };
+    const int v0 = vrow(g0);
+    const int PR = vrow(g_last) + (KS == 3 ? 3 : 1) - v0;
+    const int npix = PR * p.PC;
+
+    V2Ctx<KS, TN> c;
+    c.KT = p.KT;
+    // ---- staged patch pixels of this 8-lane group
+#pragma unroll
+    for (int i = 0; i < V2_NI; ++i) {
+        const int idx = (tid >> 3) + 32 * i;
+        int pix = -1;
+        if (idx < npix) {
+            const int pr = idx / p.PC, pc = idx - pr * p.PC;
+            if (KS == 3) {
+                const int v = v0 + pr;
+                const int n = v / (p.H + 2);
+                const int hi = v - n * (p.H + 2) - 1;
+                const int wi = c0 + pc - 1;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) pix = (n * p.H + hi) * p.W + wi;
+            } else {
+                const int wi = c0 + pc;
+                if (wi < p.W) pix = wi;
+            }
+        }
+        c.pix[i] = pix;
+    }
+    // ---- MFMA A-fragment addresses (lane -> output pixel -> patch pixel)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pp = wm * 64 + i * 32 + frow;
+        const int r = pp / p.TW, cc = pp - r * p.TW;
+        const int g = g0 + r;
+        const bool ok = pp < p.TH * p.TW && g <= g_last && c0 + cc < p.W;
+        c.a_off[i] = (ok ? ((vrow(g) - v0) * p.PC + cc) * V2_LD : 0) + 4 * fh;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nt = n_tile * (BN / 32) + wn * TN + j;
+        c.wfrag[j] = p.wf + (size_t)nt * p.KT * 1024 + lane * 4;
+    }
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ring[4][TN], stage[V2_NI];
+    // prologue: B fragments of sub-steps 0..2, patch of chunk 0
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ring[s][j] = *reinterpret_cast<const f32x4*>(c.wfrag[j] + (size_t)s * 256);
+    {
+        const int coff = p.x_off + (tid & 7) * 4;
+        float* dst = patch + (tid >> 3) * V2_LD + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < V2_NI; ++i) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            stage[i] = c.pix[i] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + (size_t)c.pix[i] * p.x_ld + coff) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < V2_NI; ++i)
+            if ((tid >> 3) + 32 * i < p.patch_cap) *reinterpret_cast<f32x4*>(dst + 32 * i * V2_LD) = stage[i];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < p.KT; ++kt) v2_kstep<KS, TN>(p, c, kt, patch, ring, stage, acc, tid);
+
+    // ---------------------------------------------------------------------- epilogue
+    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
+    const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
+    const int HoWo = p.Ho * p.Wo;
+    bool saw_nan = false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_tile * BN + wn * (BN / 2) + j * 32 + frow;
+        const bool nv = n < p.Cout;
+        const float sc = nv ? p.scale[n] : 0.f;
+        const float sh = nv ? p.shift[n] : 0.f;
+        int head_a = 0, head_k = 0;
+        if (p.out_mode == YOLO_OUT_HEAD) {
+            head_a = n / p.nc5;
+            head_k = n - head_a * p.nc5;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int tr = pp / p.TW, tc = pp - tr * p.TW;
+                const int g = g0 + tr, wo = c0 + tc;
+                if (pp >= p.TH * p.TW || g > g_last || wo >= p.W || !nv) continue;
+                const int m = g * p.W + wo;
+                float v = acc[i][j][r] * sc + sh;
+                v = act_apply2(v, p.act);
+                if (has_res) v += p.res[(size_t)m * p.r_ld + p.r_off + n];
+                if (nan_chk && v != v) saw_nan = true;
+                if (p.out_mode == YOLO_OUT_NHWC) {
+                    p.y[(size_t)m * p.y_ld + p.y_off + n] = v;
+                } else {
+                    const int img = m / HoWo;
+                    const int rem = m - img * HoWo;
+                    const int ho = rem / p.Wo;
+                    const int wo2 = rem - ho * p.Wo;
+                    if (p.out_mode == YOLO_OUT_UPSAMPLE2X) {
+                        const int W2 = 2 * p.Wo;
+                        float* d = p.y + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo2) * p.y_ld + p.y_off + n;
+                        d[0] = v;
+                        d[p.y_ld] = v;
+                        d[(size_t)W2 * p.y_ld] = v;
+                        d[(size_t)(W2 + 1) * p.y_ld] = v;
+                    } else {
+                        p.y[((size_t)((img * 3 + head_a) * p.Ho + ho) * p.Wo + wo2) * p.nc5 + head_k] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+}
+
+// fragment-order weights: [n_tile32][kt][s][lane][e] ; n = nt*32 + (lane&31),
+// ci = chunk*32 + s*8 + 4*(lane>>5) + e, (chunk, tap) = divmod(kt, ks*ks)
+__global__ void pack_weights_frag_f32(const float* __restrict__ w, float* __restrict__ wf, int cout, int cin, int ks,
+                                      int KT, long long total) {
+    const int taps = ks * ks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        const int s = (int)((i >> 8) & 3);
+        const long long rest = i >> 10;
+        const int kt = (int)(rest % KT);
+        const int nt = (int)(rest / KT);
+        const int n = nt * 32 + (lane & 31);
+        const int chunk = kt / taps, tap = kt - chunk * taps;
+        const int ci = chunk * 32 + s * 8 + 4 * (lane >> 5) + e;
+        wf[i] = n < cout ? w[((size_t)n * cin + ci) * taps + tap] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+bool v2_eligible(const yolo_conv_desc* d) { return d->stride == 1 && d->cin % 32 == 0; }
+
+size_t v2_frag_elems(int cout, int cin, int ks) {
+    if (cin % 32) return 0;
+    return (size_t)(round_up(cout, 128) / 32) * (cin / 32) * ks * ks * 1024;
+}
+
+int v2_pack(const float* w_oihw, float* wf, int cout, int cin, int ks, hipStream_t s) {
+    const long long total = (long long)v2_frag_elems(cout, cin, ks);
+    const int KT = (cin / 32) * ks * ks;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_weights_frag_f32, dim3(grid), dim3(256), 0, s, w_oihw, wf, cout, cin, ks, KT, total);
+    return check_launch("pack_weights_frag");
+}
+
+// choose TH x TW (<= 128 pixels, patch <= V2_PATCH_CAP) maximising useful MFMA rows
+static void pick_patch_tile(int H, int W, int ks, int* th, int* tw, int* prmax) {
+    if (ks == 1) { *th = 1; *tw = 128; *prmax = 1; return; }
+    double best = -1;
+    for (int TW = 4; TW <= (W < 126 ? W : 126); ++TW) {
+        int TH = 128 / TW;
+        while (TH >= 1) {
+            const int cross = (TH + H - 1) / H;             // images a tile can straddle (upper bound)
+            const int pr = TH + 2 + 2 * cross;
+            if (pr * (TW + 2) <= V2_PATCH_CAP) break;
+            --TH;
+        }
+        if (TH < 1) continue;
+        const double eff = ((double)W / (ceil_div(W, TW) * TW)) * (TH * TW / 128.0);
+        if (eff > best + 1e-9) {
+            best = eff; *th = TH; *tw = TW;
+            *prmax = TH + 2 + 2 * ((TH + H - 1) / H);
+        }
+    }
+}
+
+template <int KS, int BN>
+static int launch_v2(Conv2Args& a, hipStream_t s) {
+    a.tiles_n = ceil_div(a.Cout, BN);
+    const int tiles_r = ceil_div(a.rows_total, a.TH);
+    a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
+    const size_t lds = (size_t)2 * a.patch_cap * V2_LD * sizeof(float);
+    hipLaunchKernelGGL((conv_patch_f32<KS, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
+    return check_launch("conv_patch_f32");
+}
+
+int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
+                   const void* residual, void* y, int32_t* nan_flag, int bn, hipStream_t s) {
+    Conv2Args a;
+    a.x = (const float*)x; a.wf = wf; a.scale = scale; a.shift = shift; a.res = (const float*)residual;
+    a.y = (float*)y; a.nan_flag = nan_flag;
+    a.Cin = d->cin; a.Cout = d->cout;
+    a.x_ld = d->x_ld; a.x_off = d->x_off; a.y_ld = d->y_ld; a.y_off = d->y_off; a.r_ld = d->r_ld; a.r_off = d->r_off;
+    a.Ho = d->h; a.Wo = d->w;
+    const long long M = (long long)d->n * d->h * d->w;
+    if (M > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "conv: N*H*W exceeds int32");
+    int prmax = 1;
+    if (d->ksize == 1) {
+        a.H = 1; a.W = (int)M; a.rows_total = 1;
+        a.TH = 1; a.TW = 128; a.PC = 128;
+    } else {
+        a.H = d->h; a.W = d->w; a.rows_total = d->n * d->h;
+        pick_patch_tile(d->h, d->w, 3, &a.TH, &a.TW, &prmax);
+        a.PC = a.TW + 2;
+    }
+    a.patch_cap = round_up(prmax * a.PC, 32);
+    if (a.patch_cap > V2_PATCH_CAP) return fail(YOLO_ERR_UNSUPPORTED, "conv v2: patch too large");
+    a.tiles_w = ceil_div(a.W, a.TW);
+    a.nchunks = d->cin / 32;
+    a.KT = a.nchunks * d->ksize * d->ksize;
+    a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
+    a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
+    if (d->ksize == 3) return bn == 128 ? launch_v2<3, 128>(a, s) : launch_v2<3, 64>(a, s);
+    return bn == 128 ? launch_v2<1, 128>(a, s) : launch_v2<1, 64>(a, s);
+}
+
+}  // namespace yolo

@@ -122,18 +122,20 @@ int yolo_version(void) { return 100; }
 
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    return (size_t)coutpad_of(cout) * kpad_of(cin, ksize);
+    return v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize);
 }
 
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream) {
     if (!w_oihw || !w_packed) return fail(YOLO_ERR_ARG, "pack_weights: null pointer");
     if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "pack_weights: dtype %d", dtype);
-    const long long total = (long long)yolo_packed_weight_elems(cout, cin, ksize);
-    if (!total) return fail(YOLO_ERR_ARG, "pack_weights: bad shape");
+    if (!yolo_packed_weight_elems(cout, cin, ksize)) return fail(YOLO_ERR_ARG, "pack_weights: bad shape");
+    const long long total = (long long)v0_packed_elems(cout, cin, ksize);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)w_packed, cout, cin,
                        ksize, cin_pad_of(cin), kpad_of(cin, ksize), total);
-    return check_launch("pack_weights");
+    int rc = check_launch("pack_weights");
+    if (rc || !v2_frag_elems(cout, cin, ksize)) return rc;
+    return v2_pack(w_oihw, (float*)w_packed + total, cout, cin, ksize, (hipStream_t)stream);
 }
 
 int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream) {

@@ -14,6 +14,7 @@ Data layout in HBM (fp32 path)
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -285,7 +286,9 @@ class ModelState:
     model stays picklable / deep-copyable."""
 
     def __init__(self, model=None):
-        self._packed = {}
+        # keyed by the block MODULE (weakly): an id()-keyed cache could hand a new block the packed
+        # weights of a dead one that happened to reuse its address and parameter storage
+        self._packed = weakref.WeakKeyDictionary()
         self._plans = {}
         self.nan_check = True
         self.tile_override = None
@@ -303,17 +306,20 @@ class ModelState:
         return new
 
     def invalidate(self, drop_plans=False):
-        for pk in self._packed.values():
-            pk.stamp = None
+        for per_dev in self._packed.values():
+            for pk in per_dev.values():
+                pk.stamp = None
         if drop_plans:
-            self._packed.clear()
+            self._packed = weakref.WeakKeyDictionary()
             self._plans.clear()
 
     def packed(self, block, device):
-        key = (id(block), device.index)
-        pk = self._packed.get(key)
+        per_dev = self._packed.get(block)
+        if per_dev is None:
+            per_dev = self._packed[block] = {}
+        pk = per_dev.get(device.index)
         if pk is None:
-            pk = self._packed[key] = PackedBlock(block, device)
+            pk = per_dev[device.index] = PackedBlock(block, device)
         return pk
 
     def refresh_weights(self, blocks, device, stream):
@@ -400,6 +406,17 @@ def run_module_nchw(module, x):
             out = None
         else:
             raise NotImplementedError(type(module).__name__)
+        try:
+            return _run_module_plan(module, x, prog, cur, out, stream)
+        finally:
+            _module_state.invalidate(drop_plans=True)
+
+
+def _run_module_plan(module, x, prog, cur, out, stream):
+    lib = L.lib()
+    B, Cc, H, W = x.shape
+    cpad = cur.ld
+    if True:
         plan = Plan(prog, _module_state, x.device, _module_state.tile_override)
         _module_state.refresh_weights(plan.blocks, x.device, stream)
         xin = x.detach().float().contiguous()
@@ -416,5 +433,4 @@ def run_module_nchw(module, x):
             L.check(lib.yolo_nhwc_to_nchw(plan.phys[out.buf].data_ptr(), result.data_ptr(), B, out.C, out.H, out.W,
                                           out.ld, out.off, L.F32, stream), "yolo_nhwc_to_nchw")
         torch.cuda.current_stream().synchronize()      # plan buffers die with this call
-        _module_state._packed.clear()
     return result
