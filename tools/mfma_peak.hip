@@ -46,7 +46,27 @@ void run(const char* name, int blocks) {
     hipFree(out);
 }
 
+template <int NACC, bool LDS>
+void sustained(const char* name, int blocks, double seconds) {
+    float* out; hipMalloc(&out, sizeof(float) * blocks * 256);
+    const int iters = 4096;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double total = 0;
+    while (total < seconds) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL((k<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters, 0.37f);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double flop = 40.0 * blocks * 4 * iters * 4 * NACC * 2.0 * 32 * 32 * 2;
+        total += ms / 1e3;
+        printf("%-24s t=%5.2fs  %7.2f TFLOP/s\n", name, total, flop / ms / 1e9);
+    }
+    hipFree(out);
+}
+
 int main() {
+    sustained<4, false>("sustained regs 2blk/CU", 512, 3.0);
+    sustained<4, true>("sustained lds  2blk/CU", 512, 3.0);
     run<4, false>("regs, 4 acc, 1 blk/CU", 256);
     run<4, false>("regs, 4 acc, 2 blk/CU", 512);
     run<4, false>("regs, 4 acc, 8 blk/CU", 2048);

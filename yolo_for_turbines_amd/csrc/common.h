@@ -29,6 +29,7 @@ inline int coutpad_of(int cout) { return round_up(cout, 128); }
 // conv_f32_v2.hip ("patch + fragment stream" kernel, stride 1, cin % 32 == 0)
 bool v2_eligible(const yolo_conv_desc* d);
 size_t v2_frag_elems(int cout, int cin, int ks);
+int v2_blocks(const yolo_conv_desc* d, int bn);          // grid size the patch kernel would launch
 int v2_pack(const float* w_oihw, float* wf, int cout, int cin, int ks, hipStream_t s);
 int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
                    const void* residual, void* y, int32_t* nan_flag, int bn, hipStream_t s);

@@ -245,8 +245,11 @@ static int launch_tile(const ConvArgs& a, bool smallc, hipStream_t s) {
 // latency-bound, so among its tiles 64x64 (4+ resident blocks per CU) wins on every YOLOv3 shape;
 // stride-1 layers with cin % 32 == 0 go to the patch/fragment-stream kernel (ids 5, 6).
 static int pick_tile(const yolo_conv_desc* d) {
-    if (v2_eligible(d)) return d->cout > 64 ? 6 : 5;
-    return 4;
+    if (v2_eligible(d) && d->ksize == 3) {
+        // BN = 128 halves the A-fragment LDS reads per MFMA but needs enough blocks to fill 2 per CU
+        return v2_blocks(d, 128) >= 640 ? 6 : 5;
+    }
+    return 4;       // 1x1 (few K steps, prologue-dominated) and stride-2 layers: 64x64 register-staged tile
 }
 
 static int validate(const yolo_conv_desc* d) {
