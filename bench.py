@@ -80,7 +80,7 @@ def conv_flops(plan):
     return out
 
 
-def per_launch_times(plan, reps):
+def per_launch_times(plan, reps, x):
     """Per-launch durations (ms) with HIP events on the launch stream, `reps` passes."""
     from yolo_for_turbines_amd import _lib as L
     lib = L.lib()
@@ -96,9 +96,12 @@ def per_launch_times(plan, reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         evs[0].record()
         for i in range(n):
-            e = plan.table[i]
-            L.check(lib.yolo_conv_fwd(e.d, e.x, e.w_packed, e.scale, e.shift, e.residual, e.y, plan.nan_flag.data_ptr(),
-                                      stream), "yolo_conv_fwd")
+            if i < plan.first:                      # layers[0] runs as the stem kernel straight from NCHW
+                plan.load_input(x, stream)
+            else:
+                e = plan.table[i]
+                L.check(lib.yolo_conv_fwd(e.d, e.x, e.w_packed, e.scale, e.shift, e.residual, e.y,
+                                          plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd")
             evs[i + 1].record()
         torch.cuda.synchronize()
         acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
@@ -131,6 +134,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (tuning)")
+    ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,9 +206,14 @@ def main():
         plan = next(iter(model._engine._plans.values()))
         flops = conv_flops(plan)
         with torch.no_grad():
-            times_ms = per_launch_times(plan, reps=max(1, min(args.steps, 5)))
+            times_ms = per_launch_times(plan, max(1, min(args.steps, 5)), x)
         log("per-launch event timing done")
-        is3 = np.array([op["k"] == 3 for op in plan.prog.ops])
+        if args.per_layer:
+            for i, (op, t, f) in enumerate(zip(plan.prog.ops, times_ms, flops)):
+                cv = op["block"].conv
+                log(f"  op{i:2d} {cv.in_channels:4d}->{cv.out_channels:4d} k{op['k']} s{op['s']} {op['x'].H:3d}->{op['Ho']:3d} "
+                    f"{t * 1e3:8.1f} us {f / t / 1e9:7.1f} TF")
+        is3 = np.array([op["k"] == 3 and i >= plan.first for i, op in enumerate(plan.prog.ops)])   # MFMA 3x3 launches
         f3, t3 = float(np.sum(np.array(flops)[is3])), float(np.sum(times_ms[is3])) * 1e-3
         fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
         ach = f3 / t3 / 1e12

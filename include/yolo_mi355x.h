@@ -93,6 +93,17 @@ int yolo_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c
                       int32_t* nan_flag, void* stream);
 int yolo_nhwc_to_nchw(const void* x, float* y, int n, int c, int h, int w, int x_ld, int x_off, int dtype, void* stream);
 
+/* ---- stem: layers[0] (3 -> 32, 3x3, stride 1) straight from the NCHW input ---------------- */
+/* Replaces CNNBlock.forward for the first block (model.py:20-21,80-86) together with the
+ * NCHW -> NHWC conversion and the NaN-input guard (model.py:175): x_nchw (N,3,H,W) fp32 ->
+ * y NHWC (ld/off like yolo_conv_desc). Direct VALU convolution: the layer is bound by its output
+ * bytes, not by FLOPs. Weights as [27][cout] (yolo_stem_pack from OIHW). *nan_flag |= 1 for a NaN
+ * input element, |= 2 for a NaN output. */
+int yolo_stem_supported(int cin, int cout, int ksize, int stride);
+int yolo_stem_pack(const float* w_oihw, float* w_k_major, int cout, void* stream);
+int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scale, const float* shift, float* y,
+                  int n, int h, int w, int cout, int y_ld, int y_off, int act, int32_t* nan_flag, void* stream);
+
 /* ---- convolution blocks ---------------------------------------------------------------- */
 /* nan_flag: *nan_flag |= 2 when YOLO_FLAG_NANCHECK is set and an output element is NaN
  * (the per-layer `raise ValueError("Nan in layer")` of model.py:183-184, checked once by host). */

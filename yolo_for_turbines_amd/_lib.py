@@ -43,6 +43,10 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p]),
     "yolo_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "yolo_stem_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "yolo_stem_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "yolo_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_conv_fwd_batch": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_void_p, C.c_void_p]),

@@ -247,7 +247,7 @@ static int launch_tile(const ConvArgs& a, bool smallc, hipStream_t s) {
 static int pick_tile(const yolo_conv_desc* d) {
     if (v2_eligible(d) && d->ksize == 3) {
         // BN = 128 halves the A-fragment LDS reads per MFMA but needs enough blocks to fill 2 per CU
-        return v2_blocks(d, 128) >= 640 ? 6 : 5;
+        return (d->cout > 64 && v2_blocks(d, 128) >= 640) ? 6 : 5;
     }
     return 4;       // 1x1 (few K steps, prologue-dominated) and stride-2 layers: 64x64 register-staged tile
 }

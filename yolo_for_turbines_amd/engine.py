@@ -173,6 +173,9 @@ class PackedBlock:
         self.w = torch.empty(n, dtype=torch.float32, device=device)
         self.scale = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
         self.shift = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
+        self.stem_w = None
+        if L.lib().yolo_stem_supported(cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]):
+            self.stem_w = torch.empty(27 * cv.out_channels, dtype=torch.float32, device=device)   # [27][cout]
         self.stamp = None
 
     @staticmethod
@@ -193,6 +196,8 @@ class PackedBlock:
             w = w.float().contiguous()
         L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
                                       cv.kernel_size[0], L.F32, stream), "yolo_pack_weights")
+        if self.stem_w is not None:
+            L.check(lib.yolo_stem_pack(w.data_ptr(), self.stem_w.data_ptr(), cv.out_channels, stream), "yolo_stem_pack")
         if block.batch_norm_act:
             bn = block.batch_norm
             g, b, m, v = (t.detach().float().contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
@@ -208,7 +213,7 @@ class PackedBlock:
 class Plan:
     """Physical buffers + the ctypes launch table for one Program on one device."""
 
-    def __init__(self, prog: Program, state: "ModelState", device, tile_override=None):
+    def __init__(self, prog: Program, state: "ModelState", device, tile_override=None, use_stem=True):
         self.prog = prog
         self.device = device
         B = prog.B
@@ -236,15 +241,24 @@ class Plan:
             else:
                 self.phys[bid] = torch.empty(numel, dtype=torch.float32, device=device)
                 self.total_bytes += numel * 4
-        alloc(prog.input.buf)
+        # stem: the first block reads the caller's NCHW tensor directly (no NHWC copy of the input)
+        op0 = prog.ops[0] if prog.ops else None
+        self.stem = None
+        if (use_stem and op0 is not None and op0["x"].buf == prog.input.buf and op0["res"] is None
+                and op0["out_mode"] == L.OUT_NHWC and last_use[prog.input.buf] == 0
+                and L.lib().yolo_stem_supported(op0["block"].conv.in_channels, op0["block"].conv.out_channels, op0["k"], op0["s"])):
+            self.stem = op0
+        else:
+            alloc(prog.input.buf)
         for i in range(n_ops):
             for bid in range(len(prog.buf_numel)):
                 if first_def[bid] == i and self.phys[bid] is None:
                     alloc(bid)
             for bid in range(len(prog.buf_numel)):
-                if last_use[bid] == i and self.phys[bid] is not None and bid != prog.input.buf:
+                if last_use[bid] == i and self.phys[bid] is not None and (bid != prog.input.buf or self.stem is not None):
                     pool.setdefault(prog.buf_numel[bid], []).append(self.phys[bid])
         # ---- launch table
+        self.first = 1 if self.stem is not None else 0      # ops[first:] go through the conv launch table
         self.table = (L.ConvOp * n_ops)()
         self.pred_ops = {}
         self.blocks = []
@@ -270,15 +284,34 @@ class Plan:
             d.dtype = L.F32
             d.flags = op["flags"]
             d.tile = tile_override or 0
-            e.x = self.phys[x.buf].data_ptr()
+            if i >= self.first:
+                e.x = self.phys[x.buf].data_ptr()
             e.w_packed, e.scale, e.shift = pk.w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr()
+            if i == 0 and self.stem is not None:
+                self.stem_pk = pk
             if op["pred"] is not None:
                 self.pred_ops[op["pred"]] = (i, op["Ho"], blk.conv.out_channels // 3)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
 
+    def load_input(self, xin, stream):
+        """NCHW fp32 input -> first activation: stem kernel, or the NHWC boundary copy."""
+        lib = L.lib()
+        B, Cc, H, W = xin.shape
+        if self.stem is not None:
+            y, pk = self.stem["y"], self.stem_pk
+            L.check(lib.yolo_stem_fwd(xin.data_ptr(), pk.stem_w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr(),
+                                      self.phys[y.buf].data_ptr(), B, H, W, y.C, y.ld, y.off, _act_code(self.stem["block"]),
+                                      self.nan_flag.data_ptr(), stream), "yolo_stem_fwd")
+        else:
+            inp = self.prog.input
+            L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), self.phys[inp.buf].data_ptr(), B, Cc, H, W, inp.ld, L.F32,
+                                          self.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+
     def launch(self, stream):
-        L.check(L.lib().yolo_conv_fwd_batch(self.table, len(self.table), self.nan_flag.data_ptr(), stream),
-                "yolo_conv_fwd_batch")
+        n = len(self.table) - self.first
+        if n > 0:
+            first = C.cast(C.byref(self.table, self.first * C.sizeof(L.ConvOp)), C.POINTER(L.ConvOp))
+            L.check(L.lib().yolo_conv_fwd_batch(first, n, self.nan_flag.data_ptr(), stream), "yolo_conv_fwd_batch")
 
 
 class ModelState:
@@ -356,11 +389,8 @@ class ModelState:
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
                 xin = xin.float().contiguous()
-            lib = L.lib()
             plan.nan_flag.zero_()
-            inp = plan.prog.input
-            L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.phys[inp.buf].data_ptr(), B, Cc, H, W, inp.ld, L.F32,
-                                          plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+            plan.load_input(xin, stream)
             preds = []
             for k in range(plan.prog.n_pred):
                 i, g, c3 = plan.pred_ops[k]
@@ -417,11 +447,10 @@ def _run_module_plan(module, x, prog, cur, out, stream):
     B, Cc, H, W = x.shape
     cpad = cur.ld
     if True:
-        plan = Plan(prog, _module_state, x.device, _module_state.tile_override)
+        plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override)
         _module_state.refresh_weights(plan.blocks, x.device, stream)
         xin = x.detach().float().contiguous()
-        L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.phys[cur.buf].data_ptr(), B, Cc, H, W, cpad, L.F32,
-                                      plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+        plan.load_input(xin, stream)
         result = None
         if out is None:
             i, g, c3 = plan.pred_ops[0]
