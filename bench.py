@@ -137,9 +137,9 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import yolo_for_turbines_amd as yt
+    from yolo_for_turbines_amd import dist as ydist
+    rank, local_rank, world = ydist.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -148,44 +148,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dist = ydist.init("nccl", device) if world > 1 else None      # "nccl" is RCCL on ROCm
 
-    import yolo_for_turbines_amd as yt
     model = seeded_model(yt, args.classes, device)
     if args.tile:
         model._engine.tile_override = args.tile
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand((args.batch, 3, args.size, args.size), generator=g).to(device)   # resident in HBM before timing
-
     log(f"model + input ready on {device}")
     with torch.no_grad():
-        for i in range(args.warmup):
-            model(x)
-            torch.cuda.synchronize()
-            log(f"warmup {i} done")
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model(x)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        barrier()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
+        elapsed = ydist.timed_steps(lambda: model(x), args.steps, args.warmup, dist, device)
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
     images = args.batch * world * args.steps
     value = images / elapsed
