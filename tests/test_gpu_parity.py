@@ -279,3 +279,97 @@ def test_detect_pipeline_vs_oracle(yt):
     for b in range(3):                        # NMS exactness is defined on the boxes it was given
         want = opp.nms_indices_c(got[b], 0.45, 0.5, "center")
         np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------- training path
+def _train_block_check(yt, g, i, act, rel=2e-3):
+    cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
+    blk, x = _block(yt, i, act)
+    blk.train()
+    tag = f"cfg{i}/{act}"
+    xg = x.cuda().requires_grad_(True)
+    y = blk(xg)
+    gy = torch.from_numpy(np.random.Generator(np.random.PCG64(3000 + i)).standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(gy.cuda())
+    yc = y.detach().cpu()
+    np.testing.assert_allclose(yc.reshape(-1)[::gi.BLOCK_STRIDE].numpy(), g[f"{tag}/train"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(blk.batch_norm.running_mean.cpu().numpy(), g[f"{tag}/new_mean"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(blk.batch_norm.running_var.cpu().numpy(), g[f"{tag}/new_var"], rtol=1e-4, atol=1e-5)
+
+    def close(got, want, what):
+        scale = max(1e-6, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        assert err <= rel * scale, f"{tag} {what}: max err {err} vs scale {scale}"
+    close(xg.grad.cpu().reshape(-1)[::gi.BLOCK_STRIDE].numpy(), g[f"{tag}/dx"], "dx")
+    close(blk.conv.weight.grad.cpu().reshape(-1)[::gi.BLOCK_DW_STRIDE].numpy(), g[f"{tag}/dw"], "dw")
+    close(blk.batch_norm.weight.grad.cpu().numpy(), g[f"{tag}/dgamma"], "dgamma")
+    close(blk.batch_norm.bias.grad.cpu().numpy(), g[f"{tag}/dbeta"], "dbeta")
+    s_dx = g[f"{tag}/dx_sums"]
+    assert abs(float(xg.grad.double().abs().sum().cpu()) - s_dx[1]) <= 2e-3 * s_dx[1]
+    s_dw = g[f"{tag}/dw_sums"]
+    assert abs(float(blk.conv.weight.grad.double().abs().sum().cpu()) - s_dw[1]) <= 2e-3 * s_dw[1]
+
+
+@pytest.mark.parametrize("i", [i for i, c in enumerate(gi.BLOCK_CONFIGS) if c[4]])
+def test_block_train_forward_backward_vs_golden(yt, golden, i):
+    """BatchNorm(train) forward + running stats, and dx / dW / dgamma / dbeta for a fixed upstream
+    gradient, for every BN conv configuration (stride 1 and 2, 1x1 and 3x3, cin = 3 .. 1024)."""
+    g = golden("blocks")
+    for act in ("leaky_relu", "mish"):
+        _train_block_check(yt, g, i, act)
+
+
+@pytest.mark.parametrize("tag,act", [("leaky", "leaky_relu"), ("mish", "mish")])
+def test_network_train_step_vs_golden(yt, golden, tag, act):
+    """One fine-tune step (train.py:41-69 sequence: forward in train mode, 3 x YOLOLoss, backward,
+    SGD) against the reference: loss parts, sampled gradients, per-parameter gradient norms of ALL
+    366 parameters, updated running statistics and the SGD-updated first-layer weights."""
+    g = golden("train_step")
+    c = gi.TRAIN_CASE
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=c["nc"], activation=act)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"]).cuda()
+    tg = [torch.from_numpy(t).cuda() for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    sa = (torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)).cuda()
+    lf = yt.YOLOLoss()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    preds = m(x)
+    sums = np.stack([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for p in preds])
+    np.testing.assert_allclose(sums[:, 1], g[f"{tag}/pred_sums"][:, 1], rtol=1e-4)
+    parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+    np.testing.assert_allclose(parts.detach().cpu().numpy(), g[f"{tag}/loss_parts"], rtol=5e-4, atol=1e-5)
+    total = parts.sum()
+    total.backward()
+    named = dict(m.named_parameters())
+    for key in [k[len(tag) + 6:] for k in g.files if k.startswith(f"{tag}/grad/")]:
+        got = named[key].grad.cpu()
+        want = g[f"{tag}/grad/{key}"]
+        got = got.reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy() if got.numel() > 4096 else got.numpy()
+        scale = max(1e-7, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        # Elementwise bar. Mish is smooth: fp32 implementations agree to ~5e-5 of max|g| (measured against
+        # an fp64 run of the oracle: ours 5e-5, CPU fp32 2e-5). LeakyReLU's derivative jumps 0.1 -> 1 at
+        # u = 0, so any two fp32 implementations flip the branch on a few |u| < 1e-5 elements and single
+        # entries move by O(|dy|) (the CPU fp32 run is off by up to 6e-2 vs fp64 on some layers, ours on
+        # others); the per-parameter NORMS below stay within 5e-3 and are the real routing check.
+        tol = 1e-3 if act == "mish" else 2e-1
+        assert err <= tol * scale, f"{key}: max err {err} vs scale {scale}"
+    norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    ref = g[f"{tag}/gradnorm_all"]
+    assert norms.shape == ref.shape
+    np.testing.assert_allclose(norms, ref, rtol=5e-3, atol=1e-6 * float(ref.max()))
+    np.testing.assert_allclose(m.state_dict()["layers.0.batch_norm.running_mean"].cpu().numpy(), g[f"{tag}/rm0"], atol=1e-5)
+    np.testing.assert_allclose(m.state_dict()["layers.0.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv0"], rtol=1e-4, atol=1e-6)
+    opt.step()
+    g0 = float(np.abs(g[f"{tag}/grad/layers.0.conv.weight"]).max())      # update = lr * (momentum-free first step)
+    np.testing.assert_allclose(m.state_dict()["layers.0.conv.weight"].cpu().numpy(), g[f"{tag}/w0_after_sgd"], rtol=0,
+                               atol=1e-3 * tol * g0 + 2e-6)
+    # the packed weights follow the optimizer: a second forward must see the updated parameters
+    m.eval()
+    with torch.no_grad():
+        a = m(x)
+    assert all(torch.isfinite(t).all() for t in a)

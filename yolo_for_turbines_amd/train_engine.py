@@ -1,0 +1,398 @@
+"""Training path: train-mode forward (batch-statistics BatchNorm) and the whole backward of the
+network as ONE ``torch.autograd.Function`` over the same symbolic launch list as inference.
+
+Replaces, for the blocks of `/root/reference/code/model.py:47-225`, what PyTorch autograd does under
+`grad_scaler.scale(loss).backward()` (`/root/reference/code/train.py:53-69`): conv dgrad / wgrad,
+BatchNorm(train) forward + backward, LeakyReLU / Mish backward, skip-add, route/concat and
+nn.Upsample gradient routing. The loss (`loss.py`) and the optimizer stay PyTorch, as in the reference.
+
+Per block the forward keeps only z (raw conv output) and the block output y (the next block's input);
+u = BN(z) is recomputed from z in backward. Gradients are accumulated per BUFFER: every tensor's
+gradient lives in a buffer with the geometry (ld) of its forward buffer, so concat slices, skip
+connections and multi-consumer tensors are sums written by the gradient kernels' residual-add
+epilogues — no separate add / slice / concat kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import PackedBlock, Program, TView, _act_code, build_network_program
+
+_const_cache = {}
+
+
+def _consts(device, n=2048):
+    key = device.index
+    c = _const_cache.get(key)
+    if c is None:
+        c = _const_cache[key] = (torch.ones(n, dtype=torch.float32, device=device),
+                                 torch.zeros(n, dtype=torch.float32, device=device))
+    return c
+
+
+def _desc(B, x: TView, cin, cout, k, s, y_ld, y_off, r: TView = None, act=L.ACT_NONE, out_mode=L.OUT_NHWC, flags=0):
+    d = L.ConvDesc(n=B, h=x.H, w=x.W, cin=cin, cout=cout, ksize=k, stride=s, x_ld=x.ld, x_off=x.off, y_ld=y_ld,
+                   y_off=y_off, act=act, out_mode=out_mode, dtype=L.F32, flags=flags, tile=0)
+    if r is not None:
+        d.r_ld, d.r_off = r.ld, r.off
+        d.flags |= L.FLAG_RESIDUAL
+    return d
+
+
+class TrainPlan:
+    """Buffers for one (batch, size): activations y, raw conv outputs z, per-block statistics."""
+
+    def __init__(self, prog: Program, device):
+        self.prog, self.device, self.B = prog, device, prog.B
+        f32 = dict(dtype=torch.float32, device=device)
+        self.ybuf = [torch.empty(n, **f32) for n in prog.buf_numel]
+        self.z, self.stats = [], []
+        max_bn, max_wg = 256, 256
+        lib = L.lib()
+        for op in prog.ops:
+            blk, cv = op["block"], op["block"].conv
+            m = self.B * op["Ho"] * op["Wo"]
+            if blk.batch_norm_act:
+                self.z.append(torch.empty(m * cv.out_channels, **f32))
+                self.stats.append(torch.empty(4, cv.out_channels, **f32))        # mean, invstd, scale, shift
+                max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, cv.out_channels))
+            else:
+                self.z.append(None)
+                self.stats.append(None)
+                max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, (cv.out_channels + 31) // 32 * 32))
+            max_wg = max(max_wg, lib.yolo_wgrad_workspace_bytes(self.B, op["x"].H, op["x"].W, cv.in_channels, cv.out_channels,
+                                                                 op["k"], op["s"]))
+        self.bn_ws = torch.empty(max_bn, dtype=torch.uint8, device=device)
+        self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.dgrad_w = {}                 # op index -> packed gradient-conv weights
+
+    def view_ptr(self, v: TView):
+        return self.ybuf[v.buf].data_ptr()
+
+
+def _forward(state, model, plan: TrainPlan, x):
+    lib = L.lib()
+    prog, B, dev = plan.prog, plan.B, plan.device
+    stream = L.current_stream()
+    ones, zeros = _consts(dev)
+    blocks = [op["block"] for op in prog.ops]
+    state.refresh_weights(blocks, dev, stream)
+    plan.nan_flag.zero_()
+    xin = x.detach()
+    if xin.dtype != torch.float32 or not xin.is_contiguous():
+        xin = xin.float().contiguous()
+    inp = prog.input
+    L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.ybuf[inp.buf].data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], inp.ld,
+                                  L.F32, plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+    preds = [None] * prog.n_pred
+    for i, op in enumerate(prog.ops):
+        blk, cv = op["block"], op["block"].conv
+        pk = state.packed(blk, dev)
+        xv, yv, rv = op["x"], op["y"], op["res"]
+        cout = cv.out_channels
+        if not blk.batch_norm_act:                       # bare conv + bias (heads): single fused launch
+            g = op["Ho"]
+            out = torch.empty((B, 3, g, g, cout // 3), dtype=torch.float32, device=dev)
+            d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], 0, 0, act=L.ACT_NONE, out_mode=op["out_mode"])
+            L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr(), 0,
+                                      out.data_ptr(), plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(head)")
+            preds[op["pred"]] = out
+            continue
+        z = plan.z[i]
+        d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0)
+        L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
+                                  plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(raw)")
+        bn = blk.batch_norm
+        st = plan.stats[i]
+        m = B * op["Ho"] * op["Wo"]
+        track = bn.track_running_stats and bn.running_mean is not None
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        L.check(lib.yolo_bn_stats(z.data_ptr(), m, cout, cout, 0, bn.weight.data_ptr(), bn.bias.data_ptr(), mom, float(bn.eps),
+                                  bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                                  st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                  plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
+        if track:
+            bn.num_batches_tracked += 1
+        flag_ptr = plan.nan_flag.data_ptr() if (op["flags"] & L.FLAG_NANCHECK) else 0
+        L.check(lib.yolo_bn_act_fwd(z.data_ptr(), cout, 0, st[0].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                    plan.view_ptr(rv) if rv is not None else 0, rv.ld if rv is not None else 0,
+                                    rv.off if rv is not None else 0, plan.view_ptr(yv), yv.ld, yv.off, B, op["Ho"], op["Wo"],
+                                    cout, _act_code(blk), op["out_mode"], flag_ptr, stream), "yolo_bn_act_fwd")
+    return preds
+
+
+class _Grads:
+    """Per-buffer gradient accumulation (see module docstring)."""
+
+    def __init__(self, plan: TrainPlan):
+        self.plan = plan
+        self.state = {}                                # symbolic buf -> ("alias", TView-like) | ("own", tensor)
+        self.pool = {}
+
+    def _new(self, numel):
+        free = self.pool.get(numel)
+        if free:
+            return free.pop()
+        return torch.empty(numel, dtype=torch.float32, device=self.plan.device)
+
+    def release(self, buf):
+        st = self.state.pop(buf, None)
+        if st is not None and st[0] == "own":
+            self.pool.setdefault(st[1].numel(), []).append(st[1])
+
+    def get(self, v: TView):
+        """(ptr, ld, off) of the gradient of forward view ``v`` (must exist)."""
+        st = self.state[v.buf]
+        if st[0] == "alias":
+            ptr, ld, off0 = st[1]
+            return ptr, ld, off0 + (v.off - st[2])
+        return st[1].data_ptr(), v.ld, v.off
+
+    def add_alias(self, v: TView, ptr, ld, off):
+        """Contribution that already exists in memory (skip connection): no launch if it is the first."""
+        if v.buf not in self.state:
+            self.state[v.buf] = ("alias", (ptr, ld, off), v.off)
+            return
+        own = self._own(v)
+        ones, zeros = _consts(self.plan.device)
+        B = self.plan.B
+        L.check(L.lib().yolo_bn_act_fwd(ptr, ld, off, 0, ones.data_ptr(), zeros.data_ptr(), own.data_ptr(), v.ld, v.off,
+                                        own.data_ptr(), v.ld, v.off, B, v.H, v.W, v.C, L.ACT_NONE, L.OUT_NHWC, 0,
+                                        L.current_stream()), "grad add")
+
+    def _own(self, v: TView):
+        st = self.state.get(v.buf)
+        if st is not None and st[0] == "own":
+            return st[1]
+        raise RuntimeError("gradient buffer expected")
+
+    def target(self, v: TView):
+        """Where a gradient kernel should write its contribution to ``v``:
+        returns (out_ptr, out_ld, out_off, res_ptr, res_ld, res_off)."""
+        st = self.state.get(v.buf)
+        numel = self.plan.prog.buf_numel[v.buf]
+        if st is None:
+            t = self._new(numel)
+            if v.C != v.ld:                             # a slice is written first: the rest must read as zero
+                t.zero_()
+            self.state[v.buf] = ("own", t)
+            return t.data_ptr(), v.ld, v.off, 0, 0, 0
+        if st[0] == "alias":
+            ptr, ld, off0 = st[1]
+            t = self._new(numel)
+            if v.C != v.ld:
+                t.zero_()
+            self.state[v.buf] = ("own", t)
+            return t.data_ptr(), v.ld, v.off, ptr, ld, off0 + (v.off - st[2])
+        t = st[1]
+        return t.data_ptr(), v.ld, v.off, t.data_ptr(), v.ld, v.off
+
+
+def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_input_grad=False):
+    """need: dict param-id -> bool; seeds: {symbolic buf: gradient tensor} for stand-alone blocks.
+    Returns (dict param-id -> grad tensor, gradient buffer of the input or None)."""
+    lib = L.lib()
+    prog, B, dev = plan.prog, plan.B, plan.device
+    stream = L.current_stream()
+    ones, zeros = _consts(dev)
+    grads = {}
+    G = _Grads(plan)
+    for b, t in (seeds or {}).items():
+        G.state[b] = ("own", t)
+    dz_scratch = {}
+
+    def scratch(numel):
+        t = dz_scratch.get(numel)
+        if t is None:
+            t = dz_scratch[numel] = torch.empty(numel, dtype=torch.float32, device=dev)
+        return t
+
+    for i in range(len(prog.ops) - 1, -1, -1):
+        op = prog.ops[i]
+        blk, cv = op["block"], op["block"].conv
+        xv, yv, rv = op["x"], op["y"], op["res"]
+        cin, cout, k, s = cv.in_channels, cv.out_channels, op["k"], op["s"]
+        Ho, Wo = op["Ho"], op["Wo"]
+        m = B * Ho * Wo
+        # ---------------------------------------------------------------- dz of this block
+        if not blk.batch_norm_act:
+            dp = dpreds[op["pred"]]
+            coutp = (cout + 31) // 32 * 32
+            dz = scratch(m * coutp)
+            dz_ld = coutp
+            if dp is None:
+                dz.zero_()
+            else:
+                dp = dp.float()
+                strides = (C.c_int64 * 5)(*dp.stride())
+                L.check(lib.yolo_head_grad_to_nhwc(dp.data_ptr(), strides, dz.data_ptr(), B, Ho, cout // 3, coutp, stream),
+                        "yolo_head_grad_to_nhwc")
+            if need.get(id(cv.bias), False):
+                db = torch.empty(coutp, dtype=torch.float32, device=dev)
+                L.check(lib.yolo_bn_act_bwd(dz.data_ptr(), coutp, 0, 0, 0, 0, 0, 0, 0, 0, 0, m, coutp, L.ACT_NONE, 0, db.data_ptr(),
+                                            0, 0, 0, plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "bias grad")
+                grads[id(cv.bias)] = db[:cout]
+        else:
+            if op["out_mode"] == L.OUT_UPSAMPLE2X:      # y lives upsampled inside the concat buffer
+                gptr, gld, goff = G.get(yv)
+                dy = scratch(m * cout + 1)              # distinct key from dz of the same size
+                L.check(lib.yolo_upsample2x_bwd(gptr, gld, goff, dy.data_ptr(), cout, 0, B, Ho, Wo, cout, stream), "upsample2x_bwd")
+                dy_ptr, dy_ld, dy_off = dy.data_ptr(), cout, 0
+            else:
+                dy_ptr, dy_ld, dy_off = G.get(yv)
+            if rv is not None:                          # skip connection: d(skip input) += dy
+                G.add_alias(rv, dy_ptr, dy_ld, dy_off + 0)
+            bn, st = blk.batch_norm, plan.stats[i]
+            dz = scratch(m * cout)
+            dz_ld = cout
+            dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+            L.check(lib.yolo_bn_act_bwd(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
+                                        st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
+                                        dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, plan.bn_ws.data_ptr(),
+                                        plan.bn_ws.numel(), stream), "yolo_bn_act_bwd")
+            grads[id(bn.weight)] = dgamma
+            grads[id(bn.bias)] = dbeta
+        # ---------------------------------------------------------------- wgrad
+        if need.get(id(cv.weight), False):
+            dw = torch.empty_like(cv.weight, dtype=torch.float32)
+            L.check(lib.yolo_conv_wgrad(dz.data_ptr(), dz_ld, 0, plan.view_ptr(xv), xv.ld, xv.off, dw.data_ptr(), B, xv.H, xv.W, cin,
+                                        cout, k, s, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), stream), "yolo_conv_wgrad")
+            grads[id(cv.weight)] = dw
+        # ---------------------------------------------------------------- dgrad into the input's gradient
+        if xv.buf != prog.input.buf or want_input_grad:  # the image itself needs no gradient (train.py never asks)
+            w = cv.weight.detach()
+            n_el = lib.yolo_packed_dgrad_elems(cout, cin, k)
+            wp = plan.dgrad_w.get(i)
+            if wp is None:
+                wp = plan.dgrad_w[i] = torch.empty(n_el, dtype=torch.float32, device=dev)
+            L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), wp.data_ptr(), cout, cin, k, 1 if s == 1 else 0, stream),
+                    "yolo_pack_weights_dgrad")
+            optr, old, ooff, rptr, rld, roff = G.target(xv)
+            if s == 1:
+                coutp = (cout + 31) // 32 * 32
+                src = TView(-1, coutp, Ho, Wo, dz_ld, 0)
+                d = _desc(B, src, coutp, cin, k, 1, old, ooff)
+                if rptr:
+                    d.r_ld, d.r_off = rld, roff
+                    d.flags |= L.FLAG_RESIDUAL
+                L.check(lib.yolo_conv_fwd(d, dz.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), rptr, optr, 0, stream),
+                        "dgrad (stride 1)")
+            else:
+                L.check(lib.yolo_conv_dgrad_s2(dz.data_ptr(), dz_ld, 0, wp.data_ptr(), rptr, rld, roff, optr, old, ooff, B, Ho, Wo,
+                                               cin, cout, stream), "yolo_conv_dgrad_s2")
+        # the gradient of this block's output is consumed: recycle its buffer (unless shared with a concat slice
+        # whose other producer has not been processed yet)
+        if yv is not None and op["out_mode"] != L.OUT_UPSAMPLE2X and not _shared_later(prog, i, yv.buf):
+            G.release(yv.buf)
+        elif yv is not None and op["out_mode"] == L.OUT_UPSAMPLE2X and not _shared_later(prog, i, yv.buf):
+            G.release(yv.buf)
+    gin = G.state.get(prog.input.buf)
+    return grads, (gin[1] if (want_input_grad and gin is not None and gin[0] == "own") else None)
+
+
+def _shared_later(prog, i, buf):
+    """True if an op processed LATER in backward (index < i) also writes this buffer (concat producers)."""
+    return any(prog.ops[j]["y"] is not None and prog.ops[j]["y"].buf == buf for j in range(i))
+
+
+class YoloTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, holder, *params):
+        state, model, plan, _plist = holder
+        preds = _forward(state, model, plan, x)
+        ctx.holder = holder
+        return tuple(preds)
+
+    @staticmethod
+    def backward(ctx, *dpreds):
+        state, model, plan, plist = ctx.holder
+        need = {id(p): ctx.needs_input_grad[2 + j] for j, p in enumerate(plist)}
+        with torch.cuda.device(plan.device):
+            grads, _ = _backward(state, model, plan, list(dpreds), need)
+        out = [grads.get(id(p)) if need[id(p)] else None for p in plist]
+        return (None, None, *out)
+
+
+def forward_train(state, model, x):
+    B, Cc, H, W = x.shape
+    if Cc != model.in_channels or H != W or H % 32:
+        raise ValueError(f"input must be (B,{model.in_channels},S,S) with S a multiple of 32, got {tuple(x.shape)}")
+    with torch.cuda.device(x.device):
+        key = ("train", B, H, x.device.index)
+        plan = state._plans.get(key)
+        if plan is None:
+            prog = build_network_program(model, B, H)
+            plan = state._plans[key] = TrainPlan(prog, x.device)
+        plist = [p for p in model.parameters()]
+        holder = (state, model, plan, plist)
+        preds = YoloTrainFn.apply(x, holder, *plist)
+        if state.nan_check:
+            flag = int(plan.nan_flag.item())
+            assert not (flag & 1), "NaN in the input tensor"
+            if flag & 2:
+                raise ValueError("Nan in layer")
+    return list(preds)
+
+
+def run_module_train(module, x):
+    """Stand-alone CNNBlock / ResidualBlock in training mode under autograd (block-level parity tests)."""
+    from .engine import _module_state
+    from .model import CNNBlock, ResidualBlock
+    B, Cc, H, W = x.shape
+    with torch.cuda.device(x.device):
+        prog = Program(B)
+        cpad = (Cc + 3) // 4 * 4
+        cur = TView(prog.new_buf(H, W, cpad), Cc, H, W, cpad, 0)
+        prog.input = cur
+        if isinstance(module, CNNBlock):
+            out = prog.emit_cnn(module, cur)
+        elif isinstance(module, ResidualBlock):
+            out = prog.emit_res(module, cur, nancheck=False)
+        else:
+            raise NotImplementedError("stand-alone training is provided for CNNBlock and ResidualBlock")
+        plan = TrainPlan(prog, x.device)
+        return _ModuleTrainFn.apply(x, (_module_state, module, plan, out), *list(module.parameters()))
+
+
+class _ModuleTrainFn(torch.autograd.Function):
+    """Block-level variant: returns the block output as an NCHW tensor and also produces dx."""
+
+    @staticmethod
+    def forward(ctx, x, holder, *params):
+        state, module, plan, out = holder
+        _forward(state, module, plan, x)
+        lib = L.lib()
+        y = torch.empty((plan.B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
+        L.check(lib.yolo_nhwc_to_nchw(plan.ybuf[out.buf].data_ptr(), y.data_ptr(), plan.B, out.C, out.H, out.W, out.ld, out.off,
+                                      L.F32, L.current_stream()), "yolo_nhwc_to_nchw")
+        ctx.holder = holder
+        ctx.plist = list(module.parameters())
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        state, module, plan, out = ctx.holder
+        lib = L.lib()
+        stream = L.current_stream()
+        dev = plan.device
+        B = plan.B
+        need = {id(p): ctx.needs_input_grad[2 + j] for j, p in enumerate(ctx.plist)}
+        # seed the gradient of the block output (NCHW -> NHWC) and make the input differentiable
+        dyc = dy.float().contiguous()
+        g_out = torch.empty(plan.prog.buf_numel[out.buf], dtype=torch.float32, device=dev)
+        L.check(lib.yolo_nchw_to_nhwc(dyc.data_ptr(), g_out.data_ptr(), B, out.C, out.H, out.W, out.ld, L.F32, 0, stream), "seed")
+        grads, gx = _backward(state, module, plan, [], need, seeds={out.buf: g_out}, want_input_grad=ctx.needs_input_grad[0])
+        dx = None
+        if gx is not None:
+            Bc, Cc, H, W = ctx.xshape
+            dx = torch.empty(ctx.xshape, dtype=torch.float32, device=dev)
+            inp = plan.prog.input
+            L.check(lib.yolo_nhwc_to_nchw(gx.data_ptr(), dx.data_ptr(), Bc, Cc, H, W, inp.ld, 0, L.F32, stream), "dx")
+        return (dx, None, *[grads.get(id(p)) if need[id(p)] else None for p in ctx.plist])
