@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (tuning)")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
+    ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
     args = ap.parse_args()
 
     import yolo_for_turbines_amd as yt
@@ -159,6 +161,39 @@ def main():
     with torch.no_grad():
         elapsed = ydist.timed_steps(lambda: model(x), args.steps, args.warmup, dist, device)
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    # ---------------------------------------------------------------- fwd+bwd leg (fine-tune step)
+    train = None
+    if args.train_steps > 0:
+        from tests import golden_inputs as gi           # seeded synthetic targets / turbine anchors (data only)
+        tm = seeded_model(yt, args.train_classes, device, seed=1).train()
+        if dist is not None:
+            ydist.data_parallel(tm, dist)
+        anchors = gi.TRAIN_CASE["anchors"]
+        grids = [args.size // 32, args.size // 16, args.size // 8]
+        sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(device)
+        tg = [torch.from_numpy(t).to(device) for t in gi.synth_targets(args.batch, args.size, args.train_classes, anchors, 3 + rank)]
+        lf = yt.YOLOLoss()
+        opt = torch.optim.SGD(tm.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+
+        def train_step():                               # train.py:41-69: zero_grad, forward, 3 x loss, backward, SGD
+            opt.zero_grad(set_to_none=True)
+            preds = tm(x)
+            loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+            loss.backward()
+            opt.step()
+
+        t_el = ydist.timed_steps(train_step, args.train_steps, 2, dist, device)
+        log(f"train leg: {t_el:.3f} s for {args.train_steps} steps")
+        n_par = sum(p.numel() for p in tm.parameters())
+        train = {"metric": "images/sec at 416x416 (fwd+bwd)", "value": round(args.batch * world * args.train_steps / t_el, 2),
+                 "unit": "images/s", "ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps,
+                 "per_gpu_batch": args.batch, "num_classes": args.train_classes, "dtype": "f32",
+                 "step": "zero_grad + forward(train-mode BN) + 3 x YOLOLoss + backward + SGD",
+                 "parallelism": f"dp{world}" + (f": bucketed RCCL all-reduce of {n_par * 4 / 1e6:.1f} MB fp32 gradients" if world > 1 else ""),
+                 "algorithmic_tflops": round(3 * 65.297 * (args.size / 416.0) ** 2 * args.batch * world * args.train_steps / t_el / 1e3, 2)}
+        del tm, opt
+        torch.cuda.empty_cache()
+
     images = args.batch * world * args.steps
     value = images / elapsed
     gflop_img = GFLOP_PER_IMAGE_416_NC80 if (args.size == 416 and args.classes == 80) else None
@@ -173,6 +208,8 @@ def main():
                    "num_classes": args.classes, "parallelism": f"image-sharded x{world} (no collective)"},
     }
 
+    if train is not None:
+        result["train"] = train
     if rank == 0:
         # ------------------------------------------------------------ roofline (dominant kernel)
         plan = next(iter(model._engine._plans.values()))

@@ -66,3 +66,46 @@ def test_shard_range_is_a_partition():
                 assert 0 <= lo <= hi <= n
                 cover += list(range(lo, hi))
             assert cover == list(range(n))
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yolo_for_turbines_amd import dist as ydist
+    d = ydist.init(backend="gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(8, 4, 3, 3), (8,), (8,), (16, 8, 1, 1), (16,), (5,)]]
+    params[5].requires_grad_(False)                                   # frozen parameters get no slot
+    gb = ydist.GradBuckets(params, d, bucket_mb=4 * 300 / 1024 / 1024)   # ~300 floats per bucket -> several buckets
+    assert len(gb.buckets) >= 2 and id(params[5]) not in gb.slot
+    for step in range(2):                                             # buckets are reusable across steps
+        gb.begin()
+        for i, p in enumerate(params[:5]):
+            g = gb.view(p)
+            assert g.shape == p.shape
+            g.copy_(torch.full(p.shape, float((rank + 1) * (i + 1) * (step + 1))))
+            gb.ready(p)
+        gb.finish()
+        vals = [float(gb.view(p).mean()) for p in params[:5]]
+        q.put((rank, step, vals))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_gradient_buckets_average_over_ranks():
+    """DP parity definition of SURVEY §8e: the exchanged gradient is the arithmetic mean of the per-rank
+    gradients (rank r contributes (r+1)*k -> mean 1.5*k for two ranks), for every bucket, every step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world * 2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, step, vals in res:
+        assert vals == pytest.approx([1.5 * (i + 1) * (step + 1) for i in range(5)])

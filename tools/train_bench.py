@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Fine-tune step timing (tuning aid): forward(train) + 3 x YOLOLoss + backward + SGD."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import yolo_for_turbines_amd as yt
+from tests import golden_inputs as gi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--size", type=int, default=416)
+ap.add_argument("--classes", type=int, default=2)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+from bench import seeded_model
+m = seeded_model(yt, a.classes, dev).train()
+anchors = gi.TRAIN_CASE["anchors"]
+grids = [a.size // 32, a.size // 16, a.size // 8]
+sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(dev)
+x = torch.rand(a.batch, 3, a.size, a.size, device=dev)
+tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(a.batch, a.size, a.classes, anchors, 3)]
+lf = yt.YOLOLoss()
+opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+
+def step(timing=None):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    opt.zero_grad(set_to_none=True)
+    ev[0].record()
+    preds = m(x)
+    ev[1].record()
+    loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+    ev[2].record()
+    loss.backward()
+    ev[3].record()
+    opt.step()
+    ev[4].record()
+    torch.cuda.synchronize()
+    if timing is not None:
+        timing.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+    return float(loss)
+
+for _ in range(2):
+    step()
+t = []
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    l = step(t)
+dt = (time.perf_counter() - t0) / a.steps
+import numpy as np
+t = np.mean(np.array(t), 0)
+print(f"B={a.batch} S={a.size} nc={a.classes}: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} img/s | fwd {t[0]:.1f} loss {t[1]:.1f} bwd {t[2]:.1f} sgd {t[3]:.1f} ms | loss {l:.3f}")

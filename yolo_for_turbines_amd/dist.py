@@ -80,3 +80,90 @@ def gather_counts(count: torch.Tensor, dist=None):
     out = [torch.empty_like(count) for _ in range(dist.get_world_size())]
     dist.all_gather(out, count)
     return torch.cat(out)
+
+
+class GradBuckets:
+    """Data-parallel gradient exchange for the fused backward (no reference counterpart:
+    the reference has no distributed code, the all-reduce sits where `train.py:67-68` has nothing).
+
+    Gradients are not copied: every parameter's gradient tensor is a VIEW into a flat fp32 bucket
+    (~``bucket_mb`` each, parameters in the order the backward produces them: heads first, stem last).
+    When the backward has written the last gradient of a bucket, the bucket is all-reduced
+    asynchronously (RCCL through ``torch.distributed``; the collective runs on RCCL's stream and waits
+    for the compute stream at enqueue time), so the exchange of late layers overlaps with the
+    dgrad / wgrad of earlier ones. ``finish()`` makes the compute stream wait for every bucket and
+    turns sums into means (NCCL ``AVG`` when available). BatchNorm statistics stay per replica, as a
+    non-distributed reference run would have them per batch.
+    """
+
+    def __init__(self, params_in_backward_order, dist, bucket_mb=25.0, device=None):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.buckets = []                     # dict(buf, pending, total, work)
+        self.slot = {}                        # id(param) -> (bucket index, offset, numel, shape)
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        cur, cur_n = [], 0
+        groups = []
+        for p in params_in_backward_order:
+            if not p.requires_grad:
+                continue
+            if cur and cur_n + p.numel() > limit:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            n = sum(p.numel() for p in grp)
+            dev = device if device is not None else grp[0].device
+            buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in grp:
+                self.slot[id(p)] = (bi, off, p.numel(), tuple(p.shape))
+                off += p.numel()
+            self.buckets.append(dict(buf=buf, total=len(grp), pending=len(grp), work=None))
+        self.use_avg = False
+        if dist is not None and dist.get_backend() == "nccl":
+            self.use_avg = True
+
+    def begin(self):
+        for b in self.buckets:
+            b["pending"], b["work"] = b["total"], None
+
+    def view(self, p):
+        """Gradient storage of ``p`` inside its bucket."""
+        bi, off, n, shape = self.slot[id(p)]
+        return self.buckets[bi]["buf"].narrow(0, off, n).view(shape)
+
+    def ready(self, p):
+        """The backward has finished writing the gradient of ``p``."""
+        bi = self.slot[id(p)][0]
+        b = self.buckets[bi]
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.dist is not None and self.world > 1:
+            op = self.dist.ReduceOp.AVG if self.use_avg else self.dist.ReduceOp.SUM
+            b["work"] = self.dist.all_reduce(b["buf"], op=op, async_op=True)
+
+    def finish(self):
+        for b in self.buckets:
+            if b["pending"] != 0:
+                raise RuntimeError("a gradient bucket was never completed")
+            if b["work"] is not None:
+                b["work"].wait()
+                if not self.use_avg:
+                    b["buf"].div_(self.world)
+
+    def bytes(self):
+        return sum(b["buf"].numel() for b in self.buckets) * 4
+
+
+def data_parallel(model, dist, bucket_mb=25.0):
+    """Enable data-parallel fine-tuning on ``model`` (one process per GPU): parameters are broadcast
+    from rank 0 once, every backward all-reduces (averages) the gradients in buckets."""
+    if dist is not None and dist.get_world_size() > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    model._engine.ddp = (dist, float(bucket_mb))
+    model._engine.invalidate()
+    return model

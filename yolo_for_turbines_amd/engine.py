@@ -325,6 +325,7 @@ class ModelState:
         self._plans = {}
         self.nan_check = True
         self.tile_override = None
+        self.ddp = None                  # (torch.distributed module, bucket MB) when data-parallel (dist.data_parallel)
 
     def __getstate__(self):
         return {"nan_check": self.nan_check}

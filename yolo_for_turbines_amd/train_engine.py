@@ -70,6 +70,7 @@ class TrainPlan:
         self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.dgrad_w = {}                 # op index -> packed gradient-conv weights
+        self.buckets = None               # dist.GradBuckets when data-parallel
 
     def view_ptr(self, v: TView):
         return self.ybuf[v.buf].data_ptr()
@@ -193,7 +194,7 @@ class _Grads:
         return t.data_ptr(), v.ld, v.off, t.data_ptr(), v.ld, v.off
 
 
-def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_input_grad=False):
+def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_input_grad=False, buckets=None):
     """need: dict param-id -> bool; seeds: {symbolic buf: gradient tensor} for stand-alone blocks.
     Returns (dict param-id -> grad tensor, gradient buffer of the input or None)."""
     lib = L.lib()
@@ -201,6 +202,16 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
     stream = L.current_stream()
     ones, zeros = _consts(dev)
     grads = {}
+
+    def new_grad(p, shape=None):
+        if buckets is not None and id(p) in buckets.slot:
+            return buckets.view(p)
+        return torch.empty(tuple(p.shape) if shape is None else shape, dtype=torch.float32, device=dev)
+
+    def done(p):
+        if buckets is not None and id(p) in buckets.slot:
+            buckets.ready(p)
+
     G = _Grads(plan)
     for b, t in (seeds or {}).items():
         G.state[b] = ("own", t)
@@ -236,7 +247,10 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
                 db = torch.empty(coutp, dtype=torch.float32, device=dev)
                 L.check(lib.yolo_bn_act_bwd(dz.data_ptr(), coutp, 0, 0, 0, 0, 0, 0, 0, 0, 0, m, coutp, L.ACT_NONE, 0, db.data_ptr(),
                                             0, 0, 0, plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "bias grad")
-                grads[id(cv.bias)] = db[:cout]
+                gb = new_grad(cv.bias)
+                gb.copy_(db[:cout])                          # drop the channel padding (device-side copy)
+                grads[id(cv.bias)] = gb
+                done(cv.bias)
         else:
             if op["out_mode"] == L.OUT_UPSAMPLE2X:      # y lives upsampled inside the concat buffer
                 gptr, gld, goff = G.get(yv)
@@ -250,20 +264,23 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             bn, st = blk.batch_norm, plan.stats[i]
             dz = scratch(m * cout)
             dz_ld = cout
-            dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+            dgamma = new_grad(bn.weight)
+            dbeta = new_grad(bn.bias)
             L.check(lib.yolo_bn_act_bwd(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
                                         st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
                                         dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, plan.bn_ws.data_ptr(),
                                         plan.bn_ws.numel(), stream), "yolo_bn_act_bwd")
             grads[id(bn.weight)] = dgamma
             grads[id(bn.bias)] = dbeta
+            done(bn.weight)
+            done(bn.bias)
         # ---------------------------------------------------------------- wgrad
         if need.get(id(cv.weight), False):
-            dw = torch.empty_like(cv.weight, dtype=torch.float32)
+            dw = new_grad(cv.weight)
             L.check(lib.yolo_conv_wgrad(dz.data_ptr(), dz_ld, 0, plan.view_ptr(xv), xv.ld, xv.off, dw.data_ptr(), B, xv.H, xv.W, cin,
                                         cout, k, s, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), stream), "yolo_conv_wgrad")
             grads[id(cv.weight)] = dw
+            done(cv.weight)
         # ---------------------------------------------------------------- dgrad into the input's gradient
         if xv.buf != prog.input.buf or want_input_grad:  # the image itself needs no gradient (train.py never asks)
             w = cv.weight.detach()
@@ -314,7 +331,23 @@ class YoloTrainFn(torch.autograd.Function):
         state, model, plan, plist = ctx.holder
         need = {id(p): ctx.needs_input_grad[2 + j] for j, p in enumerate(plist)}
         with torch.cuda.device(plan.device):
-            grads, _ = _backward(state, model, plan, list(dpreds), need)
+            buckets = None
+            if state.ddp is not None:
+                buckets = plan.buckets
+                if buckets is None:
+                    from .dist import GradBuckets
+                    order = []
+                    for op in reversed(plan.prog.ops):       # the order in which _backward produces gradients
+                        blk = op["block"]
+                        if blk.batch_norm_act:
+                            order += [blk.batch_norm.weight, blk.batch_norm.bias, blk.conv.weight]
+                        else:
+                            order += [blk.conv.bias, blk.conv.weight]
+                    buckets = plan.buckets = GradBuckets(order, state.ddp[0], state.ddp[1], plan.device)
+                buckets.begin()
+            grads, _ = _backward(state, model, plan, list(dpreds), need, buckets=buckets)
+            if buckets is not None:
+                buckets.finish()
         out = [grads.get(id(p)) if need[id(p)] else None for p in plist]
         return (None, None, *out)
 
