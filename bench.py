@@ -139,6 +139,12 @@ def main():
     ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) are sent to
+    # stderr for the whole run, the result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import yolo_for_turbines_amd as yt
     from yolo_for_turbines_amd import dist as ydist
     rank, local_rank, world = ydist.env_world()
@@ -150,7 +156,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = ydist.init("nccl", device) if world > 1 else None      # "nccl" is RCCL on ROCm
+    dist = ydist.init("nccl", device)                              # "nccl" is RCCL on ROCm; None for a single process
 
     model = seeded_model(yt, args.classes, device)
     if args.tile:
@@ -267,7 +273,8 @@ def main():
                 dt = time.perf_counter() - t0
                 result["nms"]["cpu_port_boxes_per_s"] = round(nms_batch.shape[1] / dt, 1)
                 result["nms"]["cpu_port_sample"] = "1 image x 10,000 boxes, list-based port (oracle/postprocess.py:nms_list)"
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -373,3 +373,51 @@ def test_network_train_step_vs_golden(yt, golden, tag, act):
     with torch.no_grad():
         a = m(x)
     assert all(torch.isfinite(t).all() for t in a)
+
+
+# ------------------------------------------------------------- multi-scale sizes (train.py:45-46)
+@pytest.mark.parametrize("size,batch", [(320, 2), (352, 1), (480, 1), (608, 1)])
+def test_network_forward_multiscale_vs_oracle(yt, size, batch):
+    """Every S that multi-scale training / Config 5 uses gives odd grid widths (10, 11, 15, 19, 38, 76 ...):
+    tile selection and halo handling must be shape-generic. Oracle = CPU restatement on the same input."""
+    nc = 2
+    sd = onet.synth_state_dict(31, 3, nc, gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=nc)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = onet.synth_input(size, batch, size)
+    with torch.no_grad():
+        ref = onet.forward(sd, x, nc)
+        out = m(x.cuda())
+    for o, r in zip(out, ref):
+        assert tuple(o.shape) == tuple(r.shape)
+        err = float((o.cpu() - r).abs().max())
+        assert err <= TIGHT_ATOL, f"S={size}: max abs err {err}"
+
+
+def test_network_train_step_multiscale_vs_oracle(yt):
+    """Gradients at S = 160 (grids 5/10/20, batch 3) against the oracle under autograd (Mish: smooth, so the
+    elementwise comparison is meaningful — see test_network_train_step_vs_golden)."""
+    from oracle import loss as oloss
+    nc, S, B = 2, 160, 3
+    sd = onet.synth_state_dict(41, 3, nc, gain=gi.NET_GAIN)
+    x = onet.synth_input(42, B, S)
+    anchors = gi.TRAIN_CASE["anchors"]
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(B, S, nc, anchors, 43)]
+    grids = [S // 32, S // 16, S // 8]
+    sa = torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)
+    par = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd)
+    full.update(par)
+    pr = onet.forward(full, x, nc, "mish", training=True, new_stats={})
+    sum(sum(oloss.yolo_loss(pr[i], tg[i].clone(), sa[i])) for i in range(3)).backward()
+    m = yt.YOLOv3(num_classes=nc, activation="mish")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    lf = yt.YOLOLoss()
+    po = m(x.cuda())
+    sum(sum(lf(po[i], tg[i].clone().cuda(), sa[i].cuda())) for i in range(3)).backward()
+    for k, p in m.named_parameters():
+        ref_g = par[k].grad
+        rel = float((p.grad.cpu() - ref_g).abs().max() / (ref_g.abs().max() + 1e-12))
+        assert rel < 2e-3, f"{k}: {rel}"

@@ -23,8 +23,9 @@ def init(backend=None, device=None):
     """Initialise the default process group when WORLD_SIZE > 1. ``nccl`` IS RCCL on ROCm."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world == 1 or dist.is_initialized():
-        return dist if world > 1 else None
+    force = bool(os.environ.get("YOLO_FORCE_DIST"))          # exercise the collective path with one rank (tests)
+    if (world == 1 and not force) or dist.is_initialized():
+        return dist if (world > 1 or force) else None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
@@ -141,7 +142,7 @@ class GradBuckets:
         bi = self.slot[id(p)][0]
         b = self.buckets[bi]
         b["pending"] -= 1
-        if b["pending"] == 0 and self.dist is not None and self.world > 1:
+        if b["pending"] == 0 and self.dist is not None:
             op = self.dist.ReduceOp.AVG if self.use_avg else self.dist.ReduceOp.SUM
             b["work"] = self.dist.all_reduce(b["buf"], op=op, async_op=True)
 
@@ -161,7 +162,7 @@ class GradBuckets:
 def data_parallel(model, dist, bucket_mb=25.0):
     """Enable data-parallel fine-tuning on ``model`` (one process per GPU): parameters are broadcast
     from rank 0 once, every backward all-reduces (averages) the gradients in buckets."""
-    if dist is not None and dist.get_world_size() > 1:
+    if dist is not None:
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     model._engine.ddp = (dist, float(bucket_mb))
