@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
 
 // grid (W, W, B), 64 threads. word (i, cb): bit jj set <=> j = cb*64+jj > i, same class, !(iou < thr)
 __global__ __launch_bounds__(64) void nms_mask_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid, int n,
-                                                      int W, float thr, unsigned long long* __restrict__ mask) {
+                                                      int W, float thr, unsigned long long* __restrict__ mask,
+                                                      unsigned long long* __restrict__ row_any) {
     const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
     if (cb < rb) return;
     const int nv = nvalid[b];
@@ -169,19 +170,28 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const SBox* __restrict__ s
         if (!survive && cb * 64 + jj > i) word |= 1ull << jj;
     }
     mask[((size_t)b * n + i) * W + cb] = word;
+    // row_any[b][rb] bit t: row rb*64+t has a suppression bit in some LATER column block (integer OR:
+    // order-independent, so still deterministic)
+    const unsigned long long bal = __ballot(word != 0ull);
+    if (cb > rb && threadIdx.x == 0 && bal) atomicOr(&row_any[(size_t)b * W + rb], bal);
 }
 
-// one 1024-thread workgroup per image
-__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
-                                                        const int* __restrict__ nvalid, int n, int W,
-                                                        int* __restrict__ keep_idx, int* __restrict__ keep_count) {
-    extern __shared__ unsigned long long removed[];     // [W] + 1 word for the kept broadcast
+// one 256-thread workgroup per image. Per 64-row block: wave 0 resolves the diagonal word (the only
+// sequential part of greedy NMS; skipped outright when no row of the block has a diagonal bit and none
+// is already removed), then every thread owns column words and ORs in the rows that are kept AND have
+// any suppression bit at all (row_any, written by the mask kernel) — with many classes most rows
+// suppress nothing and cost no memory traffic.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
+                                                       const int* __restrict__ nvalid, const unsigned long long* __restrict__ row_any,
+                                                       int n, int W, int* __restrict__ keep_idx, int* __restrict__ keep_count) {
+    extern __shared__ unsigned long long removed[];     // [W] + 2 words: kept broadcast, kept-and-nonzero broadcast
     const int b = blockIdx.x;
     const int nv = nvalid[b];
     const int tid = threadIdx.x;
-    for (int c = tid; c <= W; c += 1024) removed[c] = 0;
+    for (int c = tid; c < W + 2; c += 256) removed[c] = 0;
     __syncthreads();
     const unsigned long long* mk = mask + (size_t)b * n * W;
+    const unsigned long long* any = row_any + (size_t)b * W;
     const int* ord = order + (size_t)b * n;
     int* out = keep_idx + (size_t)b * n;
     int count = 0;                                      // meaningful in wave 0 only
@@ -189,18 +199,23 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long
     for (int rb = 0; rb < nblk; ++rb) {
         const int rows = nv - rb * 64 < 64 ? nv - rb * 64 : 64;
         if (tid < 64) {
-            // ---- wave 0: resolve the diagonal word serially
             const int i = rb * 64 + tid;
             const unsigned long long d = tid < rows ? mk[(size_t)i * W + rb] : 0ull;
-            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
             unsigned long long rem = removed[rb];
-            unsigned long long kept = 0;
-            for (int t = 0; t < rows; ++t) {
-                if (!((rem >> t) & 1ull)) {
-                    kept |= 1ull << t;
-                    const unsigned lo = __builtin_amdgcn_readlane(dlo, t);
-                    const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
-                    rem |= ((unsigned long long)hi << 32) | lo;
+            const unsigned long long rowmask = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+            unsigned long long kept;
+            if (__ballot(d != 0ull) == 0ull) {
+                kept = rowmask & ~rem;                  // nothing inside this block suppresses anything
+            } else {
+                const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+                kept = 0;
+                for (int t = 0; t < rows; ++t) {
+                    if (!((rem >> t) & 1ull)) {
+                        kept |= 1ull << t;
+                        const unsigned lo = __builtin_amdgcn_readlane(dlo, t);
+                        const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
+                        rem |= ((unsigned long long)hi << 32) | lo;
+                    }
                 }
             }
             if (tid < rows && ((kept >> tid) & 1ull)) {
@@ -208,24 +223,31 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long
                 out[pos] = ord[i];
             }
             count += __popcll(kept);
-            if (tid == 0) removed[W] = kept;
+            if (tid == 0) {
+                removed[W] = kept;
+                removed[W + 1] = kept & any[rb];        // kept rows that suppress something in a later block
+            }
         }
         __syncthreads();
-        const unsigned long long kept = removed[W];
-        // ---- all waves: OR kept rows into later column words. 4 row groups x 256 columns.
-        const int rg = tid >> 8, cl = tid & 255;
-        for (int c = rb + 1 + cl; c < nblk; c += 256) {   // column blocks >= nblk were never written
-            unsigned long long acc = 0;
-            for (int t = rg; t < rows; t += 4)
-                if ((kept >> t) & 1ull) acc |= mk[(size_t)(rb * 64 + t) * W + c];
-            if (acc) atomicOr(&removed[c], acc);
+        unsigned long long work = removed[W + 1];
+        if (work) {
+            for (int c = rb + 1 + tid; c < nblk; c += 256) {     // column blocks >= nblk were never written
+                unsigned long long acc = 0;
+                unsigned long long wk = work;
+                while (wk) {
+                    const int t = __builtin_ctzll(wk);
+                    wk &= wk - 1;
+                    acc |= mk[(size_t)(rb * 64 + t) * W + c];
+                }
+                if (acc) removed[c] |= acc;             // column c is owned by exactly this thread
+            }
         }
         __syncthreads();
     }
     if (tid == 0) keep_count[b] = count;
 }
 
-struct NmsWs { int* nvalid; int* order; SBox* sbox; unsigned long long* mask; size_t total; };
+struct NmsWs { int* nvalid; unsigned long long* row_any; int* order; SBox* sbox; unsigned long long* mask; size_t zero_bytes; size_t total; };
 
 static NmsWs carve(void* base, int b, int n) {
     const int W = ceil_div(n > 0 ? n : 1, 64);
@@ -233,6 +255,8 @@ static NmsWs carve(void* base, int b, int n) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return (char*)base + o; };
     NmsWs w;
     w.nvalid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1));
+    w.row_any = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
+    w.zero_bytes = off;                                 // nvalid + row_any are zeroed by one memset per call
     w.order = (int*)take(sizeof(int) * (size_t)b * n);
     w.sbox = (SBox*)take(sizeof(SBox) * (size_t)b * n);
     w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)b * n * W);
@@ -279,18 +303,18 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
     NmsWs w = carve(workspace, b, n);
     if (workspace_bytes < w.total) return fail(YOLO_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", workspace_bytes, w.total);
     const int W = ceil_div(n, 64);
-    if ((size_t)(W + 1) * 8 > 60 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "nms: n = %d too large", n);
+    if ((size_t)(W + 2) * 8 > 60 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "nms: n = %d too large", n);
     if (b > 65535 || W > 65535) return fail(YOLO_ERR_UNSUPPORTED, "nms: grid too large");
-    if (hipMemsetAsync(w.nvalid, 0, sizeof(int) * (size_t)b, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
+    if (hipMemsetAsync(w.nvalid, 0, w.zero_bytes, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
     hipLaunchKernelGGL(nms_rank_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, boxes, n, obj_threshold, center, w.order,
                        w.sbox, w.nvalid);
     int rc = check_launch("nms_rank");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, b), dim3(64), 0, st, w.sbox, w.nvalid, n, W, (float)iou_threshold, w.mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, b), dim3(64), 0, st, w.sbox, w.nvalid, n, W, (float)iou_threshold, w.mask, w.row_any);
     rc = check_launch("nms_mask");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(b), dim3(1024), (size_t)(W + 1) * 8, st, w.mask, w.order, w.nvalid, n, W, keep_idx,
-                       keep_count);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(b), dim3(256), (size_t)(W + 2) * 8, st, w.mask, w.order, w.nvalid, w.row_any, n, W,
+                       keep_idx, keep_count);
     return check_launch("nms_scan");
 }
 
