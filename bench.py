@@ -49,6 +49,7 @@ def host_cores():
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_H16_MFMA_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA peak (not the 2:1-sparsity marketing figure)
 GFLOP_PER_IMAGE_416_NC80 = 65.864     # BASELINE.md §2 (75 convs, 2*Ho*Wo*Cout*Cin*k^2)
 
 
@@ -135,6 +136,8 @@ def main():
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (tuning)")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
+                    help="compute dtype of the forward leg (BASELINE configs[1] = fp32; fp16 / bf16 = configs 4-5 arithmetic)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
     ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
     args = ap.parse_args()
@@ -161,6 +164,7 @@ def main():
     model = seeded_model(yt, args.classes, device)
     if args.tile:
         model._engine.tile_override = args.tile
+    model._engine.compute_dtype = args.dtype
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand((args.batch, 3, args.size, args.size), generator=g).to(device)   # resident in HBM before timing
     log(f"model + input ready on {device}")
@@ -207,8 +211,9 @@ def main():
     result = {
         "metric": "images/sec at 416x416 (fwd)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: batch {args.batch}/GPU {args.size}x{args.size} fp32 inference, "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch {args.batch}/GPU {args.size}x{args.size} {args.dtype} inference, "
                                f"{args.classes}-class head, YOLOv3 forward (75 fused conv launches)",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": args.size,
                    "num_classes": args.classes, "parallelism": f"image-sharded x{world} (no collective)"},
@@ -232,10 +237,12 @@ def main():
         f3, t3 = float(np.sum(np.array(flops)[is3])), float(np.sum(times_ms[is3])) * 1e-3
         fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
         ach = f3 / t3 / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_H16_MFMA_TFLOPS
         result["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
+                       else f"conv_patch_h16 (3x3 launches, v_mfma_f32_32x32x16_{'f16' if args.dtype == 'fp16' else 'bf16'})"),
             "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
             "algorithmic_gflop_per_step": round(f3 / 1e9, 2),
             "all_conv_launches": {"achieved": round(fall / tall / 1e12, 2), "launches_per_step": len(flops),

@@ -55,7 +55,8 @@ typedef struct yolo_conv_desc {
     int32_t r_ld, r_off;    /* residual "  (YOLO_FLAG_RESIDUAL), same spatial size as y    */
     int32_t act;            /* YOLO_ACT_*                                                  */
     int32_t out_mode;       /* YOLO_OUT_*                                                  */
-    int32_t dtype;          /* YOLO_F32 (this round); activations and packed weights       */
+    int32_t dtype;          /* YOLO_F32, YOLO_F16 or YOLO_BF16: activations (x, residual, y) and   */
+                            /* packed weights; accumulation, scale/shift and heads stay fp32       */
     int32_t flags;          /* YOLO_FLAG_*                                                 */
     int32_t tile;           /* 0 = library heuristic; else forced tile id (tuning/tests)   */
 } yolo_conv_desc;
@@ -78,6 +79,9 @@ int yolo_version(void);
  * [cout_pad128/32][cin/32][k*k][4][64 lanes][4] streamed straight into registers by the
  * stride-1 patch kernel. */
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize);
+/* bytes of the packed buffer for a dtype. YOLO_F16 / YOLO_BF16: fragment order for
+ * v_mfma_f32_32x32x16_{f16,bf16}: [cout_pad128/32][cin/32][k*k][2][64 lanes][8 halfs] (cin % 32 == 0). */
+size_t yolo_packed_weight_bytes(int cout, int cin, int ksize, int dtype);
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream);
 /* inverse (for gradients / checkpoint export): packed -> OIHW */
 int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream);
@@ -96,13 +100,14 @@ int yolo_nhwc_to_nchw(const void* x, float* y, int n, int c, int h, int w, int x
 /* ---- stem: layers[0] (3 -> 32, 3x3, stride 1) straight from the NCHW input ---------------- */
 /* Replaces CNNBlock.forward for the first block (model.py:20-21,80-86) together with the
  * NCHW -> NHWC conversion and the NaN-input guard (model.py:175): x_nchw (N,3,H,W) fp32 ->
- * y NHWC (ld/off like yolo_conv_desc). Direct VALU convolution: the layer is bound by its output
+ * y NHWC in `dtype` (fp32, or fp16/bf16 for the 16-bit path; ld/off like yolo_conv_desc). Direct VALU
+ * convolution in fp32: the layer is bound by its output
  * bytes, not by FLOPs. Weights as [27][cout] (yolo_stem_pack from OIHW). *nan_flag |= 1 for a NaN
  * input element, |= 2 for a NaN output. */
 int yolo_stem_supported(int cin, int cout, int ksize, int stride);
 int yolo_stem_pack(const float* w_oihw, float* w_k_major, int cout, void* stream);
-int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scale, const float* shift, float* y,
-                  int n, int h, int w, int cout, int y_ld, int y_off, int act, int32_t* nan_flag, void* stream);
+int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scale, const float* shift, void* y,
+                  int n, int h, int w, int cout, int y_ld, int y_off, int act, int dtype, int32_t* nan_flag, void* stream);
 
 /* ---- convolution blocks ---------------------------------------------------------------- */
 /* nan_flag: *nan_flag |= 2 when YOLO_FLAG_NANCHECK is set and an output element is NaN

@@ -421,3 +421,63 @@ def test_network_train_step_multiscale_vs_oracle(yt):
         ref_g = par[k].grad
         rel = float((p.grad.cpu() - ref_g).abs().max() / (ref_g.abs().max() + 1e-12))
         assert rel < 2e-3, f"{k}: {rel}"
+
+
+# ------------------------------------------------------------- bf16 / fp16 path (BASELINE configs 4-5)
+H16_TOL = {"bf16": 2.5e-2, "fp16": 4e-3}       # block level, relative to max|y|: one rounding of x, w and y to 8 / 11 bits
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("i", [i for i, c in enumerate(gi.BLOCK_CONFIGS) if c[0] % 32 == 0])
+def test_conv_block_16bit_vs_oracle(yt, i, dtype):
+    """Every 16-bit-eligible conv config (1x1, 3x3 stride 1 and 2, bare heads) against the fp32 oracle;
+    the tolerance is the rounding of inputs / weights / outputs to the 16-bit format, not more."""
+    from yolo_for_turbines_amd import engine
+    cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
+    blk, x = _block(yt, i, "leaky_relu")
+    p = gi.block_params(i, cin, cout, k, bn)
+    sd = {"b.conv.weight": torch.from_numpy(p["w"])}
+    if bn:
+        sd.update({"b.batch_norm.weight": torch.from_numpy(p["gamma"]), "b.batch_norm.bias": torch.from_numpy(p["beta"]),
+                   "b.batch_norm.running_mean": torch.from_numpy(p["mean"]), "b.batch_norm.running_var": torch.from_numpy(p["var"])})
+    else:
+        sd["b.conv.bias"] = torch.from_numpy(p["bias"])
+    with torch.no_grad():
+        ref = onet.cnn_block(sd, dict(prefix="b", cin=cin, cout=cout, k=k, stride=s, bn=bn), x, "leaky_relu")
+    engine._module_state.compute_dtype = dtype
+    try:
+        with torch.no_grad():
+            y = blk(x.cuda()).cpu()
+    finally:
+        engine._module_state.compute_dtype = None
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    err = float((y - ref).abs().max() / ref.abs().max())
+    assert err <= H16_TOL[dtype], f"cfg {i} {dtype}: rel err {err}"
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 1.2e-1)])
+def test_network_forward_16bit_vs_oracle(yt, dtype, tol):
+    """Whole forward in fp16 / bf16 (explicit compute dtype and through torch.autocast) against the fp32
+    oracle, next to what the oracle itself loses under CPU autocast(bf16) on the same weights."""
+    c = gi.NET_CASES["nc80_s96_b2_leaky"]
+    m = _model(yt, c)
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    x = onet.synth_input(c["xseed"], 2, 160)
+    with torch.no_grad():
+        ref = onet.forward(sd, x, c["nc"])
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref_bf16 = onet.forward(sd, x, c["nc"])
+        m._engine.compute_dtype = dtype
+        out = m(x.cuda())
+        m._engine.compute_dtype = None
+        with torch.autocast("cuda", dtype=torch.float16 if dtype == "fp16" else torch.bfloat16):
+            out_ac = m(x.cuda())
+    for o, oa, r, rb in zip(out, out_ac, ref, ref_bf16):
+        assert o.dtype == torch.float32 and tuple(o.shape) == tuple(r.shape)
+        assert torch.equal(o, oa)                                   # autocast selects the same path
+        scale = float(r.abs().max())
+        err = float((o.cpu() - r).abs().max()) / scale
+        err_cpu_bf16 = float((rb.float() - r).abs().max()) / scale
+        assert err <= tol, f"{dtype}: rel err {err} (CPU autocast bf16 loses {err_cpu_bf16})"
+        if dtype == "bf16":
+            assert err <= 3 * err_cpu_bf16 + 1e-2

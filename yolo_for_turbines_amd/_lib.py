@@ -35,6 +35,7 @@ _SIGS = {
     "yolo_last_error": (C.c_char_p, []),
     "yolo_version": (C.c_int, []),
     "yolo_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "yolo_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "yolo_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "yolo_unpack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "yolo_bn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
@@ -46,7 +47,7 @@ _SIGS = {
     "yolo_stem_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "yolo_stem_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "yolo_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_conv_fwd_batch": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_void_p, C.c_void_p]),

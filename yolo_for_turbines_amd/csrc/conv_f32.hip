@@ -254,7 +254,7 @@ static int pick_tile(const yolo_conv_desc* d) {
 
 static int validate(const yolo_conv_desc* d) {
     if (!d) return fail(YOLO_ERR_ARG, "conv: null descriptor");
-    if (d->dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "conv: dtype %d not built (fp32 only)", d->dtype);
+    if (d->dtype < 0 || d->dtype > 2) return fail(YOLO_ERR_ARG, "conv: dtype %d", d->dtype);
     if (d->ksize != 1 && d->ksize != 3) return fail(YOLO_ERR_UNSUPPORTED, "conv: ksize %d", d->ksize);
     if (d->stride != 1 && d->stride != 2) return fail(YOLO_ERR_UNSUPPORTED, "conv: stride %d", d->stride);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0) return fail(YOLO_ERR_ARG, "conv: bad shape");
@@ -274,6 +274,7 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     if (!x || !w || !scale || !shift || !y) return fail(YOLO_ERR_ARG, "conv: null pointer");
     if ((d->flags & YOLO_FLAG_RESIDUAL) && !residual) return fail(YOLO_ERR_ARG, "conv: residual flag without pointer");
     if ((d->flags & YOLO_FLAG_NANCHECK) && !nan_flag) return fail(YOLO_ERR_ARG, "conv: nancheck flag without pointer");
+    if (d->dtype != YOLO_F32) return conv_h16_launch(d, x, w, scale, shift, residual, y, nan_flag, s);
     ConvArgs a;
     a.x = (const float*)x; a.w = (const float*)w; a.scale = scale; a.shift = shift;
     a.res = (const float*)residual; a.y = (float*)y; a.nan_flag = nan_flag;

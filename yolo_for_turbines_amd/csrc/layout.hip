@@ -77,7 +77,19 @@ __global__ void nchw_to_nhwc_small(const float* __restrict__ x, float* __restric
 }
 
 // generic tiled transpose for larger C (32x32 tiles through LDS), used by tests / debug taps
-__global__ void nchw_to_nhwc_tiled(const float* __restrict__ x, float* __restrict__ y, int c, int hw, int c_pad, int* nan_flag) {
+__device__ __forceinline__ unsigned short cvt16(float f, int dtype) {
+    if (dtype == YOLO_BF16) { __bf16 h = (__bf16)f; return *reinterpret_cast<unsigned short*>(&h); }
+    _Float16 h = (_Float16)f;
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+__device__ __forceinline__ float cvt32(unsigned short v, int dtype) {
+    if (dtype == YOLO_BF16) return __uint_as_float((unsigned)v << 16);
+    _Float16 h = *reinterpret_cast<_Float16*>(&v);
+    return (float)h;
+}
+
+__global__ void nchw_to_nhwc_tiled(const float* __restrict__ x, void* __restrict__ yv, int c, int hw, int c_pad, int dtype, int* nan_flag) {
+    float* y = reinterpret_cast<float*>(yv);
     __shared__ float t[32][33];
     const int img = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -91,18 +103,27 @@ __global__ void nchw_to_nhwc_tiled(const float* __restrict__ x, float* __restric
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
         const int pp = p0 + r, cc = c0 + threadIdx.x;
-        if (pp < hw && cc < c_pad) y[((size_t)img * hw + pp) * c_pad + cc] = t[threadIdx.x][r];
+        if (pp < hw && cc < c_pad) {
+            if (dtype == YOLO_F32) y[((size_t)img * hw + pp) * c_pad + cc] = t[threadIdx.x][r];
+            else reinterpret_cast<unsigned short*>(yv)[((size_t)img * hw + pp) * c_pad + cc] = cvt16(t[threadIdx.x][r], dtype);
+        }
     }
     if (bad && nan_flag) atomicOr(nan_flag, 1);
 }
 
-__global__ void nhwc_to_nchw_tiled(const float* __restrict__ x, float* __restrict__ y, int c, int hw, int x_ld, int x_off) {
+__global__ void nhwc_to_nchw_tiled(const void* __restrict__ xv, float* __restrict__ y, int c, int hw, int x_ld, int x_off, int dtype) {
+    const float* x = reinterpret_cast<const float*>(xv);
     __shared__ float t[32][33];
     const int img = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
         const int pp = p0 + r, cc = c0 + threadIdx.x;
-        t[r][threadIdx.x] = (pp < hw && cc < c) ? x[((size_t)img * hw + pp) * x_ld + x_off + cc] : 0.f;
+        float v = 0.f;
+        if (pp < hw && cc < c) {
+            const size_t idx = ((size_t)img * hw + pp) * x_ld + x_off + cc;
+            v = dtype == YOLO_F32 ? x[idx] : cvt32(reinterpret_cast<const unsigned short*>(xv)[idx], dtype);
+        }
+        t[r][threadIdx.x] = v;
     }
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -120,6 +141,13 @@ extern "C" {
 const char* yolo_last_error(void) { return yolo::err_buf(); }
 int yolo_version(void) { return 100; }
 
+size_t yolo_packed_weight_bytes(int cout, int cin, int ksize, int dtype) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    if (dtype == YOLO_F32) return (v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize)) * sizeof(float);
+    if (dtype == YOLO_F16 || dtype == YOLO_BF16) return cin % 32 ? 0 : h16_frag_elems(cout, cin, ksize) * 2;
+    return 0;
+}
+
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
     return v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize);
@@ -127,6 +155,10 @@ size_t yolo_packed_weight_elems(int cout, int cin, int ksize) {
 
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream) {
     if (!w_oihw || !w_packed) return fail(YOLO_ERR_ARG, "pack_weights: null pointer");
+    if (dtype == YOLO_F16 || dtype == YOLO_BF16) {
+        if (!yolo_packed_weight_bytes(cout, cin, ksize, dtype)) return fail(YOLO_ERR_UNSUPPORTED, "pack_weights: 16-bit needs cin %% 32 == 0");
+        return h16_pack(w_oihw, w_packed, cout, cin, ksize, dtype, (hipStream_t)stream);
+    }
     if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "pack_weights: dtype %d", dtype);
     if (!yolo_packed_weight_elems(cout, cin, ksize)) return fail(YOLO_ERR_ARG, "pack_weights: bad shape");
     const long long total = (long long)v0_packed_elems(cout, cin, ksize);
@@ -161,26 +193,26 @@ int yolo_bn_fold(const float* gamma, const float* beta, const float* mean, const
 int yolo_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int dtype, int32_t* nan_flag,
                       void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0 || c_pad < c) return fail(YOLO_ERR_ARG, "nchw_to_nhwc: bad arguments");
-    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "nchw_to_nhwc: dtype %d", dtype);
+    if (dtype < 0 || dtype > 2) return fail(YOLO_ERR_UNSUPPORTED, "nchw_to_nhwc: dtype %d", dtype);
     const int hw = h * w;
-    if (c_pad <= 8) {
+    if (c_pad <= 8 && dtype == YOLO_F32) {
         const long long total = (long long)n * hw;
         const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL(nchw_to_nhwc_small, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (float*)y, n, c, hw, c_pad,
                            nan_flag);
     } else {
         dim3 grid(ceil_div(hw, 32), ceil_div(c_pad, 32), n), block(32, 8);
-        hipLaunchKernelGGL(nchw_to_nhwc_tiled, grid, block, 0, (hipStream_t)stream, x, (float*)y, c, hw, c_pad, nan_flag);
+        hipLaunchKernelGGL(nchw_to_nhwc_tiled, grid, block, 0, (hipStream_t)stream, x, y, c, hw, c_pad, dtype, nan_flag);
     }
     return check_launch("nchw_to_nhwc");
 }
 
 int yolo_nhwc_to_nchw(const void* x, float* y, int n, int c, int h, int w, int x_ld, int x_off, int dtype, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0 || x_ld < c) return fail(YOLO_ERR_ARG, "nhwc_to_nchw: bad arguments");
-    if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "nhwc_to_nchw: dtype %d", dtype);
+    if (dtype < 0 || dtype > 2) return fail(YOLO_ERR_UNSUPPORTED, "nhwc_to_nchw: dtype %d", dtype);
     const int hw = h * w;
     dim3 grid(ceil_div(hw, 32), ceil_div(c, 32), n), block(32, 8);
-    hipLaunchKernelGGL(nhwc_to_nchw_tiled, grid, block, 0, (hipStream_t)stream, (const float*)x, y, c, hw, x_ld, x_off);
+    hipLaunchKernelGGL(nhwc_to_nchw_tiled, grid, block, 0, (hipStream_t)stream, x, y, c, hw, x_ld, x_off, dtype);
     return check_launch("nhwc_to_nchw");
 }
 

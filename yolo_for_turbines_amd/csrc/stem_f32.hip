@@ -16,11 +16,19 @@ namespace yolo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ unsigned short stem_cvt(float f, int dtype) {
+    if (dtype == YOLO_BF16) { __bf16 h = (__bf16)f; return *reinterpret_cast<unsigned short*>(&h); }
+    _Float16 h = (_Float16)f;
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+
+// DT: YOLO_F32 writes fp32; YOLO_F16 / YOLO_BF16 write 16-bit activations for conv_h16.hip
 template <int COUT>
 __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, const float* __restrict__ wt,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ y, int N, int H, int W, int y_ld, int y_off, int act,
-                                                   int* nan_flag) {
+                                                   void* __restrict__ yv, int N, int H, int W, int y_ld, int y_off, int act,
+                                                   int dtype, int* nan_flag) {
+    float* y = reinterpret_cast<float*>(yv);
     // weights [27][COUT] in LDS: every lane reads the same address (broadcast, conflict-free).
     // (Reading them through the scalar cache was tried first: hipcc hoists all 864 s_loads and
     // spills 800 SGPRs.)
@@ -63,20 +71,33 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
             }
     }
     if (bad_in) atomicOr(nan_flag, 1);                    // NaN in the INPUT tensor (model.py:175)
-    float* dst = y + (size_t)p * y_ld + y_off;
     bool bad = false;
 #pragma unroll
-    for (int co = 0; co < COUT; co += 4) {
-        f32x4 v;
+    for (int co = 0; co < COUT; ++co) {
+        float t = acc[co] * scale[co] + shift[co];
+        if (act == YOLO_ACT_LEAKY) t = t > 0.f ? t : t * 0.1f;
+        else if (act == YOLO_ACT_MISH) { float sp = t > 20.f ? t : log1pf(__expf(t)); t = t * tanhf(sp); }
+        bad |= (t != t);
+        acc[co] = t;
+    }
+    if (dtype == YOLO_F32) {
+        float* dst = y + (size_t)p * y_ld + y_off;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = acc[co + e] * scale[co + e] + shift[co + e];
-            if (act == YOLO_ACT_LEAKY) t = t > 0.f ? t : t * 0.1f;
-            else if (act == YOLO_ACT_MISH) { float sp = t > 20.f ? t : log1pf(__expf(t)); t = t * tanhf(sp); }
-            bad |= (t != t);
-            v[e] = t;
+        for (int co = 0; co < COUT; co += 4) {
+            f32x4 v = {acc[co], acc[co + 1], acc[co + 2], acc[co + 3]};
+            *reinterpret_cast<f32x4*>(dst + co) = v;
         }
-        *reinterpret_cast<f32x4*>(dst + co) = v;
+    } else {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        unsigned short* dst = reinterpret_cast<unsigned short*>(yv) + (size_t)p * y_ld + y_off;
+#pragma unroll
+        for (int co = 0; co < COUT; co += 8) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = (unsigned)stem_cvt(acc[co + 2 * e], dtype) | ((unsigned)stem_cvt(acc[co + 2 * e + 1], dtype) << 16);
+            *reinterpret_cast<u32x4*>(dst + co) = o;
+        }
     }
     if (bad) atomicOr(nan_flag, 2);
 }
@@ -103,15 +124,16 @@ int yolo_stem_pack(const float* w_oihw, float* w_k_major, int cout, void* stream
     return check_launch("stem_pack");
 }
 
-int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scale, const float* shift, float* y, int n, int h,
-                  int w, int cout, int y_ld, int y_off, int act, int32_t* nan_flag, void* stream) {
+int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scale, const float* shift, void* y, int n, int h,
+                  int w, int cout, int y_ld, int y_off, int act, int dtype, int32_t* nan_flag, void* stream) {
     if (!x_nchw || !w_k_major || !scale || !shift || !y || !nan_flag) return fail(YOLO_ERR_ARG, "stem: null pointer");
-    if (cout != 32 || n <= 0 || h <= 0 || w <= 0 || (y_ld & 3) || (y_off & 3) || y_ld < cout)
-        return fail(YOLO_ERR_UNSUPPORTED, "stem: only 3 -> 32 channels, y_ld/y_off multiples of 4");
+    const int al = dtype == YOLO_F32 ? 3 : 7;
+    if (cout != 32 || n <= 0 || h <= 0 || w <= 0 || (y_ld & al) || (y_off & al) || y_ld < cout || dtype < 0 || dtype > 2)
+        return fail(YOLO_ERR_UNSUPPORTED, "stem: only 3 -> 32 channels, y_ld/y_off multiples of 16 bytes");
     const long long total = (long long)n * h * w;
     if (total > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "stem: too many pixels");
     hipLaunchKernelGGL((stem3x3_f32<32>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
-                       w_k_major, scale, shift, y, n, h, w, y_ld, y_off, act, nan_flag);
+                       w_k_major, scale, shift, y, n, h, w, y_ld, y_off, act, dtype, nan_flag);
     return check_launch("stem3x3_f32");
 }
 

@@ -23,6 +23,22 @@ import torch.nn as nn
 
 from . import _lib as L
 
+_DT = {"fp32": (L.F32, torch.float32), "fp16": (L.F16, torch.float16), "bf16": (L.BF16, torch.bfloat16)}
+
+
+def resolve_dtype(requested=None):
+    """Compute dtype of a forward: an explicit request ("fp32" | "fp16" | "bf16"), else the active
+    ``torch.autocast`` dtype (the reference wraps its training forward in autocast, train.py:53), else fp32."""
+    if requested is not None:
+        if requested not in _DT:
+            raise ValueError(f"compute dtype must be one of {sorted(_DT)}, got {requested!r}")
+        return requested
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        return "bf16" if dt == torch.bfloat16 else "fp16"
+    return "fp32"
+
+
 BN_NOTE = "nn.BatchNorm2d eval semantics: scale = gamma / sqrt(var + eps), shift = beta - mean * scale"
 
 
@@ -106,7 +122,7 @@ class Program:
         self.n_pred += 1
 
 
-def build_network_program(model, B, S):
+def build_network_program(model, B, S, ch_align=4):
     """Walk ``model.layers`` the way the reference forward does (model.py:172-193)."""
     from .model import CNNBlock, ResidualBlock, ScalePredictionBlock
     layers = list(model.layers)
@@ -124,7 +140,7 @@ def build_network_program(model, B, S):
             pair[ri] = pair[i] = dict(cu=c, cr=cr)
             c = c + cr
     prog = Program(B)
-    cin_pad = (model.in_channels + 3) // 4 * 4
+    cin_pad = (model.in_channels + ch_align - 1) // ch_align * ch_align
     cur = TView(prog.new_buf(S, S, cin_pad), model.in_channels, S, S, cin_pad, 0)
     prog.input = cur
     concat_view = {}                                  # upsample layer index -> TView of the whole concat
@@ -165,16 +181,22 @@ def build_network_program(model, B, S):
 class PackedBlock:
     """Device-side packed weights + folded BN of one CNNBlock."""
 
-    def __init__(self, block, device):
+    def __init__(self, block, device, dtype="fp32"):
         cv = block.conv
-        n = L.lib().yolo_packed_weight_elems(cv.out_channels, cv.in_channels, cv.kernel_size[0])
-        if n == 0:
-            raise ValueError("unsupported conv shape")
-        self.w = torch.empty(n, dtype=torch.float32, device=device)
+        self.dtype = dtype
+        self.code = _DT[dtype][0]
+        lib = L.lib()
+        stem_ok = bool(lib.yolo_stem_supported(cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]))
+        n = lib.yolo_packed_weight_bytes(cv.out_channels, cv.in_channels, cv.kernel_size[0], self.code)
+        if n == 0 and not (stem_ok and dtype != "fp32"):
+            raise NotImplementedError(f"conv {cv.in_channels}->{cv.out_channels} k{cv.kernel_size[0]} has no {dtype} kernel "
+                                      "(16-bit needs cin % 32 == 0)")
+        self.w = torch.empty(max(n, 16), dtype=torch.uint8, device=device)
         self.scale = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
         self.shift = torch.empty(cv.out_channels, dtype=torch.float32, device=device)
         self.stem_w = None
-        if L.lib().yolo_stem_supported(cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]):
+        self.packs_conv = n != 0
+        if stem_ok:
             self.stem_w = torch.empty(27 * cv.out_channels, dtype=torch.float32, device=device)   # [27][cout]
         self.stamp = None
 
@@ -194,8 +216,9 @@ class PackedBlock:
         w = cv.weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
-        L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
-                                      cv.kernel_size[0], L.F32, stream), "yolo_pack_weights")
+        if self.packs_conv:
+            L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
+                                          cv.kernel_size[0], self.code, stream), "yolo_pack_weights")
         if self.stem_w is not None:
             L.check(lib.yolo_stem_pack(w.data_ptr(), self.stem_w.data_ptr(), cv.out_channels, stream), "yolo_stem_pack")
         if block.batch_norm_act:
@@ -213,9 +236,11 @@ class PackedBlock:
 class Plan:
     """Physical buffers + the ctypes launch table for one Program on one device."""
 
-    def __init__(self, prog: Program, state: "ModelState", device, tile_override=None, use_stem=True):
+    def __init__(self, prog: Program, state: "ModelState", device, tile_override=None, use_stem=True, dtype="fp32"):
         self.prog = prog
         self.device = device
+        self.dtype = dtype
+        self.code, self.tdtype = _DT[dtype]
         B = prog.B
         n_ops = len(prog.ops)
         # ---- liveness pooling of activation buffers
@@ -239,8 +264,8 @@ class Plan:
             if free:
                 self.phys[bid] = free.pop()
             else:
-                self.phys[bid] = torch.empty(numel, dtype=torch.float32, device=device)
-                self.total_bytes += numel * 4
+                self.phys[bid] = torch.empty(numel, dtype=self.tdtype, device=device)
+                self.total_bytes += numel * self.phys[bid].element_size()
         # stem: the first block reads the caller's NCHW tensor directly (no NHWC copy of the input)
         op0 = prog.ops[0] if prog.ops else None
         self.stem = None
@@ -264,7 +289,7 @@ class Plan:
         self.blocks = []
         for i, op in enumerate(prog.ops):
             blk = op["block"]
-            pk = state.packed(blk, device)
+            pk = state.packed(blk, device, dtype)
             self.blocks.append(blk)
             x, y, r = op["x"], op["y"], op["res"]
             e = self.table[i]
@@ -281,7 +306,7 @@ class Plan:
                 e.residual = self.phys[r.buf].data_ptr()
             d.act = _act_code(blk)
             d.out_mode = op["out_mode"]
-            d.dtype = L.F32
+            d.dtype = self.code
             d.flags = op["flags"]
             d.tile = tile_override or 0
             if i >= self.first:
@@ -301,10 +326,10 @@ class Plan:
             y, pk = self.stem["y"], self.stem_pk
             L.check(lib.yolo_stem_fwd(xin.data_ptr(), pk.stem_w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr(),
                                       self.phys[y.buf].data_ptr(), B, H, W, y.C, y.ld, y.off, _act_code(self.stem["block"]),
-                                      self.nan_flag.data_ptr(), stream), "yolo_stem_fwd")
+                                      self.code, self.nan_flag.data_ptr(), stream), "yolo_stem_fwd")
         else:
             inp = self.prog.input
-            L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), self.phys[inp.buf].data_ptr(), B, Cc, H, W, inp.ld, L.F32,
+            L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), self.phys[inp.buf].data_ptr(), B, Cc, H, W, inp.ld, self.code,
                                           self.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
 
     def launch(self, stream):
@@ -325,6 +350,7 @@ class ModelState:
         self._plans = {}
         self.nan_check = True
         self.tile_override = None
+        self.compute_dtype = None        # None: follow torch.autocast (fp32 outside it); or "fp32" / "fp16" / "bf16"
         self.ddp = None                  # (torch.distributed module, bucket MB) when data-parallel (dist.data_parallel)
 
     def __getstate__(self):
@@ -347,18 +373,18 @@ class ModelState:
             self._packed = weakref.WeakKeyDictionary()
             self._plans.clear()
 
-    def packed(self, block, device):
+    def packed(self, block, device, dtype="fp32"):
         per_dev = self._packed.get(block)
         if per_dev is None:
             per_dev = self._packed[block] = {}
-        pk = per_dev.get(device.index)
+        pk = per_dev.get((device.index, dtype))
         if pk is None:
-            pk = per_dev[device.index] = PackedBlock(block, device)
+            pk = per_dev[(device.index, dtype)] = PackedBlock(block, device, dtype)
         return pk
 
-    def refresh_weights(self, blocks, device, stream):
+    def refresh_weights(self, blocks, device, stream, dtype="fp32"):
         for blk in blocks:
-            pk = self.packed(blk, device)
+            pk = self.packed(blk, device, dtype)
             if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk):
                 pk.refresh(blk, stream)
 
@@ -381,12 +407,15 @@ class ModelState:
                                       "call model.eval() for inference")
         with torch.cuda.device(x.device):
             stream = L.current_stream()
-            key = (B, H, x.device.index, self.tile_override)
+            dt = resolve_dtype(self.compute_dtype)
+            key = (B, H, x.device.index, self.tile_override, dt)
             plan = self._plans.get(key)
             if plan is None:
-                prog = build_network_program(model, B, H)
-                plan = self._plans[key] = Plan(prog, self, x.device, self.tile_override)
-            self.refresh_weights(plan.blocks, x.device, stream)
+                prog = build_network_program(model, B, H, ch_align=8 if dt != "fp32" else 4)
+                plan = self._plans[key] = Plan(prog, self, x.device, self.tile_override, dtype=dt)
+                if dt != "fp32" and plan.stem is None:
+                    raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
+            self.refresh_weights(plan.blocks, x.device, stream, dt)
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
                 xin = xin.float().contiguous()
@@ -422,10 +451,12 @@ def run_module_nchw(module, x):
         return train_engine.run_module_train(module, x)
     lib = L.lib()
     B, Cc, H, W = x.shape
+    dt = resolve_dtype(_module_state.compute_dtype)
     with torch.cuda.device(x.device):
         stream = L.current_stream()
         prog = Program(B)
-        cpad = (Cc + 3) // 4 * 4
+        al = 8 if dt != "fp32" else 4
+        cpad = (Cc + al - 1) // al * al
         cur = TView(prog.new_buf(H, W, cpad), Cc, H, W, cpad, 0)
         prog.input = cur
         if isinstance(module, CNNBlock):
@@ -438,18 +469,18 @@ def run_module_nchw(module, x):
         else:
             raise NotImplementedError(type(module).__name__)
         try:
-            return _run_module_plan(module, x, prog, cur, out, stream)
+            return _run_module_plan(module, x, prog, cur, out, stream, dt)
         finally:
             _module_state.invalidate(drop_plans=True)
 
 
-def _run_module_plan(module, x, prog, cur, out, stream):
+def _run_module_plan(module, x, prog, cur, out, stream, dt="fp32"):
     lib = L.lib()
     B, Cc, H, W = x.shape
     cpad = cur.ld
     if True:
-        plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override)
-        _module_state.refresh_weights(plan.blocks, x.device, stream)
+        plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override, dtype=dt)
+        _module_state.refresh_weights(plan.blocks, x.device, stream, dt)
         xin = x.detach().float().contiguous()
         plan.load_input(xin, stream)
         result = None
@@ -461,6 +492,6 @@ def _run_module_plan(module, x, prog, cur, out, stream):
         if out is not None:
             result = torch.empty((B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
             L.check(lib.yolo_nhwc_to_nchw(plan.phys[out.buf].data_ptr(), result.data_ptr(), B, out.C, out.H, out.W,
-                                          out.ld, out.off, L.F32, stream), "yolo_nhwc_to_nchw")
+                                          out.ld, out.off, plan.code, stream), "yolo_nhwc_to_nchw")
         torch.cuda.current_stream().synchronize()      # plan buffers die with this call
     return result
