@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="compute dtype of the forward leg (BASELINE configs[1] = fp32; fp16 / bf16 = configs 4-5 arithmetic)")
+    ap.add_argument("--config5", action="store_true",
+                    help="also time BASELINE config 5 per-GPU shape: batch 16, 608x608 fp16 forward + decode + per-image NMS")
     ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
     ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
     args = ap.parse_args()
@@ -204,6 +206,25 @@ def main():
         del tm, opt
         torch.cuda.empty_cache()
 
+    # ---------------------------------------------------------------- config 5 leg (optional)
+    cfg5 = None
+    if args.config5:
+        m5 = seeded_model(yt, 80, device, seed=2)
+        m5._engine.compute_dtype = "fp16"
+        x5 = torch.rand((16, 3, 608, 608), generator=g).to(device)
+        anchors5 = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+                    [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
+        sa5 = [torch.tensor(a).to(device) * gsz for a, gsz in zip(anchors5, (19, 38, 76))]
+
+        def step5():
+            with torch.no_grad():
+                yt.detect(m5(x5), sa5, 0.45, 0.5, "center")
+        t5 = ydist.timed_steps(step5, 10, 2, dist, device)
+        cfg5 = {"workload": "BASELINE configs[4] per-GPU shape: batch 16, 608x608 fp16 forward + decode (22,743 boxes/image) + per-image NMS",
+                "value": round(16 * world * 10 / t5, 2), "unit": "images/s", "ms_per_step": round(t5 / 10 * 1e3, 3)}
+        del m5
+        torch.cuda.empty_cache()
+
     images = args.batch * world * args.steps
     value = images / elapsed
     gflop_img = GFLOP_PER_IMAGE_416_NC80 if (args.size == 416 and args.classes == 80) else None
@@ -221,6 +242,8 @@ def main():
 
     if train is not None:
         result["train"] = train
+    if cfg5 is not None:
+        result["config5"] = cfg5
     if rank == 0:
         # ------------------------------------------------------------ roofline (dominant kernel)
         plan = next(iter(model._engine._plans.values()))

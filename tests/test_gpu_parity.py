@@ -376,7 +376,7 @@ def test_network_train_step_vs_golden(yt, golden, tag, act):
 
 
 # ------------------------------------------------------------- multi-scale sizes (train.py:45-46)
-@pytest.mark.parametrize("size,batch", [(320, 2), (352, 1), (480, 1), (608, 1)])
+@pytest.mark.parametrize("size,batch", [(32, 3), (64, 1), (320, 2), (352, 1), (480, 1), (608, 1)])
 def test_network_forward_multiscale_vs_oracle(yt, size, batch):
     """Every S that multi-scale training / Config 5 uses gives odd grid widths (10, 11, 15, 19, 38, 76 ...):
     tile selection and halo handling must be shape-generic. Oracle = CPU restatement on the same input."""
@@ -481,3 +481,31 @@ def test_network_forward_16bit_vs_oracle(yt, dtype, tol):
         assert err <= tol, f"{dtype}: rel err {err} (CPU autocast bf16 loses {err_cpu_bf16})"
         if dtype == "bf16":
             assert err <= 3 * err_cpu_bf16 + 1e-2
+
+
+def test_config5_shape_fp16_forward_decode_nms(yt):
+    """BASELINE config 5 per-GPU shape family: 608x608 fp16 forward (grids 19/38/76 -> 22,743 boxes per
+    image), device decode in the reference's concatenation order, per-image NMS. Forward vs the fp32 oracle
+    within the fp16 tolerance; NMS kept indices bit-exact against the C oracle ON THE BOXES IT WAS GIVEN."""
+    nc, S, B = 80, 608, 2
+    sd = onet.synth_state_dict(51, 3, nc, gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=nc)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m._engine.compute_dtype = "fp16"
+    x = onet.synth_input(52, B, S)
+    with torch.no_grad():
+        ref = onet.forward(sd, x[:1], nc)
+        preds = m(x.cuda())
+    for o, r in zip(preds, ref):
+        assert tuple(o.shape[1:]) == tuple(r.shape[1:])
+        assert float((o[:1].cpu() - r).abs().max()) <= 2e-2 * float(r.abs().max())
+    anchors = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+               [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
+    sa = [torch.tensor(a) * p.shape[2] for a, p in zip(anchors, preds)]
+    boxes, keep, count = yt.detect(preds, sa, 0.45, 0.5, "center")
+    assert boxes.shape == (B, 22743, 6)
+    bh = boxes.cpu().numpy()
+    for b in range(B):
+        want = opp.nms_indices_c(bh[b], 0.45, 0.5, "center")
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
