@@ -36,23 +36,24 @@ LAYERS = {   # name: (H, cin, cout, k, stride)
 }
 
 
-def run(name, batch, tile, reps, residual, dev):
+def run(name, batch, tile, reps, residual, dev, dtype="fp32"):
     H, cin, cout, k, s = LAYERS[name]
     lib = L.lib()
     cpad = (cin + 3) // 4 * 4
     Ho = (H + 2 * (k // 2) - k) // s + 1
-    x = torch.randn(batch * H * H * cpad, device=dev)
+    code, tdt = {"fp32": (L.F32, torch.float32), "fp16": (L.F16, torch.float16), "bf16": (L.BF16, torch.bfloat16)}[dtype]
+    x = torch.randn(batch * H * H * cpad, device=dev).to(tdt)
     w = torch.randn(cout, cin, k, k, device=dev) * (1.0 / (cin * k * k)) ** 0.5
-    wp = torch.empty(lib.yolo_packed_weight_elems(cout, cin, k), device=dev)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, k, code), dtype=torch.uint8, device=dev)
     stream = L.current_stream()
-    L.check(lib.yolo_pack_weights(w.data_ptr(), wp.data_ptr(), cout, cin, k, L.F32, stream))
+    L.check(lib.yolo_pack_weights(w.data_ptr(), wp.data_ptr(), cout, cin, k, code, stream))
     scale = torch.rand(cout, device=dev) + 0.5
     shift = torch.randn(cout, device=dev) * 0.1
-    y = torch.empty(batch * Ho * Ho * cout, device=dev)
-    r = torch.randn(batch * Ho * Ho * cout, device=dev) if residual else None
+    y = torch.empty(batch * Ho * Ho * cout, device=dev, dtype=tdt)
+    r = torch.randn(batch * Ho * Ho * cout, device=dev).to(tdt) if residual else None
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     d = L.ConvDesc(n=batch, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=s, x_ld=cpad, x_off=0, y_ld=cout, y_off=0,
-                   r_ld=cout, r_off=0, act=L.ACT_LEAKY, out_mode=L.OUT_NHWC, dtype=L.F32,
+                   r_ld=cout, r_off=0, act=L.ACT_LEAKY, out_mode=L.OUT_NHWC, dtype=code,
                    flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
 
     def launch():
@@ -69,7 +70,7 @@ def run(name, batch, tile, reps, residual, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     gflop = 2.0 * batch * Ho * Ho * cout * cin * k * k / 1e9
-    picked = lib.yolo_conv_pick_tile(d) if tile == 0 else tile
+    picked = (lib.yolo_conv_pick_tile(d) if dtype == "fp32" else 0) if tile == 0 else tile
     print(f"{name:12s} tile={picked} {ms * 1e3:8.1f} us  {gflop / ms:7.2f} TFLOP/s  ({gflop:.1f} GFLOP)", flush=True)
     return ms
 
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--tile", default="0", help="tile id, comma list, or 'all'")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--residual", action="store_true")
+    ap.add_argument("--dtype", default="fp32")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     names = list(LAYERS) if a.layer == "all" else a.layer.split(",")
@@ -88,7 +90,7 @@ def main():
     tiles = list(range(1, nt + 1)) if a.tile == "all" else [int(t) for t in a.tile.split(",")]
     for n in names:
         for t in tiles:
-            run(n, a.batch, t, a.reps, a.residual, dev)
+            run(n, a.batch, t, a.reps, a.residual, dev, a.dtype)
 
 
 if __name__ == "__main__":
