@@ -70,15 +70,29 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
         if (vch < c4 && lane < g.lanes) {
             float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
             int run = 0;
-            for (int p = p0 + lane; p < p1; p += g.lanes) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(z + (size_t)p * ld + off + vch * 4);
+            const float* zp = z + off + vch * 4;
+            int p = p0 + lane;
+            // 4 independent 16-byte loads in flight per thread (one-at-a-time left the kernel at ~45 % of
+            // the achievable HBM rate: latency-bound, not bandwidth-bound)
+            for (; p + 3 * g.lanes < p1; p += 4 * g.lanes) {
+                f32x4 x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fs[e] += x[e]; fq[e] += x[e] * x[e]; }
-                if (++run == 64) {                       // flush short fp32 runs into fp64
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(zp + (size_t)(p + u * g.lanes) * ld);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { fs[e] += x[u][e]; fq[e] += x[u][e] * x[u][e]; }
+                run += 4;
+                if (run >= 64) {                         // flush short fp32 runs into fp64
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
                     run = 0;
                 }
+            }
+            for (; p < p1; p += g.lanes) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(zp + (size_t)p * ld);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fs[e] += x[e]; fq[e] += x[e] * x[e]; }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
@@ -218,21 +232,37 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             }
             float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
             int run = 0;
-            for (int p = p0 + lane; p < p1; p += g.lanes) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + vch * 4);
-                f32x4 x = {0, 0, 0, 0};
-                if (mean) x = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + vch * 4);
+            auto accum = [&](const f32x4& d, const f32x4& x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float du = mean ? d[e] * act_grad((x[e] - mu[e]) * sc[e] + sh[e], act) : d[e];
                     fs[e] += du;
                     fq[e] += du * ((x[e] - mu[e]) * is[e]);
                 }
-                if (++run == 64) {
+            };
+            int p = p0 + lane;
+            for (; p + g.lanes < p1; p += 2 * g.lanes) {          // 4 loads in flight (2 pixels x {dy, z})
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + vch * 4);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + (size_t)(p + g.lanes) * dy_ld + dy_off + vch * 4);
+                f32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+                if (mean) {
+                    x0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + vch * 4);
+                    x1 = *reinterpret_cast<const f32x4*>(z + (size_t)(p + g.lanes) * z_ld + z_off + vch * 4);
+                }
+                accum(d0, x0);
+                accum(d1, x1);
+                run += 2;
+                if (run >= 64) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
                     run = 0;
                 }
+            }
+            for (; p < p1; p += g.lanes) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + vch * 4);
+                f32x4 x = {0, 0, 0, 0};
+                if (mean) x = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + vch * 4);
+                accum(d, x);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 
 static int red_blocks(int m, int* pix_per_block) {
     int nblk = (m + 255) / 256;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     *pix_per_block = (m + nblk - 1) / nblk;
     return (m + *pix_per_block - 1) / *pix_per_block;
