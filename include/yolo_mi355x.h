@@ -124,41 +124,46 @@ int yolo_conv_num_tiles(void);
  * train.py:53-67 for the blocks of model.py:47-121 (nn.Conv2d, nn.BatchNorm2d(train), LeakyReLU /
  * Mish, skip add, nn.Upsample). Reductions are deterministic (fixed order, fp64 across threads). */
 size_t yolo_bn_workspace_bytes(int m, int c);
-/* z: raw conv output, m = N*H*W pixels, c channels (ld/off as usual). Batch mean / biased variance ->
+/* Activation / gradient tensors (z, y, residual, dy, dz, x, dx, dup) are NHWC in `dtype` (YOLO_F32, or
+ * YOLO_BF16 / YOLO_F16 for the autocast training path of train.py:53: 16-bit storage, fp32 arithmetic,
+ * one rounding at the store); statistics, parameters and parameter gradients are always fp32.
+ *
+ * z: raw conv output, m = N*H*W pixels, c channels (ld/off as usual). Batch mean / biased variance ->
  * mean, invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta (the train kernels evaluate
  * (z - mean)*scale + shift in that order, like PyTorch); running stats are updated in place like
  * nn.BatchNorm2d (momentum, unbiased variance) unless the pointers are NULL. */
-int yolo_bn_stats(const float* z, int m, int c, int ld, int off, const float* gamma, const float* beta, float momentum,
+int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gamma, const float* beta, float momentum,
                   float eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                  float* shift, void* workspace, size_t workspace_bytes, void* stream);
+                  float* shift, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* y = act((z - mean)*scale + shift) [+ residual] (mean may be NULL = 0); out_mode YOLO_OUT_NHWC or
  * YOLO_OUT_UPSAMPLE2X. */
-int yolo_bn_act_fwd(const float* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const float* residual,
-                    int r_ld, int r_off, float* y, int y_ld, int y_off, int n, int h, int w, int c, int act, int out_mode,
-                    int32_t* nan_flag, void* stream);
+int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const void* residual,
+                    int r_ld, int r_off, void* y, int y_ld, int y_off, int n, int h, int w, int c, int act, int out_mode,
+                    int dtype, int32_t* nan_flag, void* stream);
 /* Backward of act(BN(z)): dy -> dgamma, dbeta, dz (gradient of the raw conv output). gamma == NULL:
  * bare conv (model.py:86) -> only dbeta (= bias gradient) is produced and dz is dy itself. */
-int yolo_bn_act_bwd(const float* dy, int dy_ld, int dy_off, const float* z, int z_ld, int z_off, const float* gamma,
+int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_ld, int z_off, const float* gamma,
                     const float* mean, const float* invstd, const float* scale, const float* shift, int m, int c, int act,
-                    float* dgamma, float* dbeta, float* dz, int dz_ld, int dz_off, void* workspace, size_t workspace_bytes,
+                    float* dgamma, float* dbeta, void* dz, int dz_ld, int dz_off, int dtype, void* workspace, size_t workspace_bytes,
                     void* stream);
 /* gradient of nn.Upsample(scale_factor=2): dx(n,h,w,c) = sum of the 2x2 destinations in dup(n,2h,2w,.) */
-int yolo_upsample2x_bwd(const float* dup, int d_ld, int d_off, float* dx, int x_ld, int x_off, int n, int h, int w, int c,
-                        void* stream);
-/* dW (OIHW fp32) = sum over pixels dz (x) x; n,h,w = INPUT dims of the conv; dz has the output dims. */
-size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride);
-int yolo_conv_wgrad(const float* dz, int dz_ld, int dz_off, const float* x, int x_ld, int x_off, float* dw_oihw, int n, int h,
-                    int w, int cin, int cout, int ksize, int stride, void* workspace, size_t workspace_bytes, void* stream);
-/* Weights of the input-gradient convolution. flip = 1: stride-1 convs — the result is a packed buffer for
- * yolo_conv_fwd with (cin' = cout rounded up to 32, cout' = cin, same ksize, stride 1): dx = conv(dz, W').
- * flip = 0: operand of yolo_conv_dgrad_s2. */
-size_t yolo_packed_dgrad_elems(int cout, int cin, int ksize);
-int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, void* stream);
+int yolo_upsample2x_bwd(const void* dup, int d_ld, int d_off, void* dx, int x_ld, int x_off, int n, int h, int w, int c,
+                        int dtype, void* stream);
+/* dW (OIHW fp32) = sum over pixels dz (x) x; n,h,w = INPUT dims of the conv; dz has the output dims.
+ * 16-bit operands with cin % 32 == 0 run on the bf16/f16 matrix cores, everything else on the f32 ones. */
+size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride, int dtype);
+int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* dw_oihw, int n, int h,
+                    int w, int cin, int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Weights of the input-gradient convolution, from the fp32 OIHW master weights. flip = 1: stride-1 convs —
+ * the result is a packed buffer for yolo_conv_fwd (same dtype) with (cin' = cout rounded up to 32,
+ * cout' = cin, same ksize, stride 1): dx = conv(dz, W'). flip = 0: operand of yolo_conv_dgrad_s2 (always fp32). */
+size_t yolo_packed_dgrad_bytes(int cout, int cin, int ksize, int flip, int dtype);
+int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, int dtype, void* stream);
 /* dx (n,2ho,2wo,cin) = transposed 3x3 stride-2 conv of dz (n,ho,wo,cout) [+ residual] */
-int yolo_conv_dgrad_s2(const float* dz, int dz_ld, int dz_off, const void* w_packed, const float* residual, int r_ld, int r_off,
-                       float* dx, int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, void* stream);
-/* upstream gradient in the head layout (B,3,g,g,D), any strides -> NHWC (B,g,g,ld), channel a*D+k, pads 0 */
-int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, float* out, int b, int g, int d, int ld, void* stream);
+int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_packed, const void* residual, int r_ld, int r_off,
+                       void* dx, int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, void* stream);
+/* upstream gradient in the head layout (B,3,g,g,D) fp32, any strides -> NHWC (B,g,g,ld) in dtype, channel a*D+k, pads 0 */
+int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream);
 
 /* ---- post-processing ------------------------------------------------------------------- */
 /* Replaces cells_to_boxes (utils.py:86-148) for one scale.

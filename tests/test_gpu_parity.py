@@ -509,3 +509,92 @@ def test_config5_shape_fp16_forward_decode_nms(yt):
     for b in range(B):
         want = opp.nms_indices_c(bh[b], 0.45, 0.5, "center")
         np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+
+
+# ------------------------------------------------------------- 16-bit fine-tune step (Config 4 arithmetic)
+H16_TRAIN_TOL = {"bf16": 4e-2, "fp16": 6e-3}    # block level, relative to max|reference|
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("i", [i for i, c in enumerate(gi.BLOCK_CONFIGS) if c[4] and c[0] % 32 == 0])
+def test_block_train_16bit_vs_golden(yt, golden, i, dtype):
+    """Train-mode block in bf16 / fp16 storage (what torch.autocast gives the reference, train.py:53):
+    BatchNorm(train) output and running stats, dx / dW / dgamma / dbeta against the fp32 reference,
+    within the rounding of activations and gradients to the 16-bit format."""
+    from yolo_for_turbines_amd import engine
+    g = golden("blocks")
+    cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
+    act = "leaky_relu"
+    blk, x = _block(yt, i, act)
+    blk.train()
+    tag = f"cfg{i}/{act}"
+    xg = x.cuda().requires_grad_(True)
+    engine._module_state.compute_dtype = dtype
+    try:
+        y = blk(xg)
+        gy = torch.from_numpy(np.random.Generator(np.random.PCG64(3000 + i)).standard_normal(tuple(y.shape), dtype=np.float32))
+        y.backward(gy.cuda())
+    finally:
+        engine._module_state.compute_dtype = None
+    tol = H16_TRAIN_TOL[dtype]
+
+    def close(got, want, what, t=tol):
+        scale = max(1e-6, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        assert err <= t * scale, f"{tag} {dtype} {what}: max err {err} vs scale {scale} ({err / scale:.3g})"
+
+    def close_l2(got, want, what):
+        # gradients: a 16-bit rounding of z flips LeakyReLU's branch on the few elements with |u| ~ 0 and moves
+        # single entries by O(|dy|), so the bar is the relative L2 error, not the max
+        err = float(np.linalg.norm(got.astype(np.float64) - want) / (np.linalg.norm(want) + 1e-30))
+        assert err <= tol, f"{tag} {dtype} {what}: relative L2 error {err:.3g}"
+    close(y.detach().cpu().reshape(-1)[::gi.BLOCK_STRIDE].numpy(), g[f"{tag}/train"], "y")
+    close(blk.batch_norm.running_mean.cpu().numpy(), g[f"{tag}/new_mean"], "running_mean", 1e-2)
+    close(blk.batch_norm.running_var.cpu().numpy(), g[f"{tag}/new_var"], "running_var", 1e-2)
+    close_l2(xg.grad.cpu().reshape(-1)[::gi.BLOCK_STRIDE].numpy(), g[f"{tag}/dx"], "dx")
+    close_l2(blk.conv.weight.grad.cpu().reshape(-1)[::gi.BLOCK_DW_STRIDE].numpy(), g[f"{tag}/dw"], "dw")
+    close_l2(blk.batch_norm.weight.grad.cpu().numpy(), g[f"{tag}/dgamma"], "dgamma")
+    close_l2(blk.batch_norm.bias.grad.cpu().numpy(), g[f"{tag}/dbeta"], "dbeta")
+
+
+@pytest.mark.parametrize("dtype,cos_min,norm_tol", [("fp16", 0.995, 0.03), ("bf16", 0.95, 0.12)])
+def test_network_train_step_16bit_vs_golden(yt, golden, dtype, cos_min, norm_tol):
+    """One fine-tune step under torch.autocast (the reference's train.py:53 context) on the 16-bit kernels,
+    Mish network (smooth, see test_network_train_step_vs_golden): loss parts and the direction / size of
+    every parameter gradient against the fp32 reference."""
+    g = golden("train_step")
+    tag = "mish"
+    c = gi.TRAIN_CASE
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=c["nc"], activation="mish")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"]).cuda()
+    tg = [torch.from_numpy(t).cuda() for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    sa = (torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)).cuda()
+    lf = yt.YOLOLoss()
+    with torch.autocast("cuda", dtype=torch.float16 if dtype == "fp16" else torch.bfloat16):
+        preds = m(x)
+    assert all(p.dtype == torch.float32 for p in preds)
+    parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+    np.testing.assert_allclose(parts.detach().cpu().numpy(), g[f"{tag}/loss_parts"], rtol=norm_tol, atol=1e-3)
+    parts.sum().backward()
+    named = dict(m.named_parameters())
+    worst_cos, worst_key = 1.0, None
+    for key in [k[len(tag) + 6:] for k in g.files if k.startswith(f"{tag}/grad/")]:
+        got = named[key].grad.cpu()
+        want = g[f"{tag}/grad/{key}"]
+        got = got.reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy() if got.numel() > 4096 else got.numpy()
+        if np.abs(want).max() < 1e-12:
+            continue
+        cos = float((got.astype(np.float64) * want).sum() / (np.linalg.norm(got.astype(np.float64)) * np.linalg.norm(want) + 1e-30))
+        if cos < worst_cos:
+            worst_cos, worst_key = cos, key
+    assert worst_cos >= cos_min, f"{dtype}: gradient direction of {worst_key}: cos {worst_cos}"
+    norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    ref = g[f"{tag}/gradnorm_all"]
+    big = ref > 1e-3 * ref.max()
+    ratio = norms[big] / ref[big]
+    assert np.all(np.abs(ratio - 1) <= norm_tol), f"{dtype}: gradient-norm ratio range {ratio.min():.3f} .. {ratio.max():.3f}"
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())

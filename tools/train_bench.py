@@ -11,10 +11,12 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--size", type=int, default=416)
 ap.add_argument("--classes", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 from bench import seeded_model
 m = seeded_model(yt, a.classes, dev).train()
+m._engine.compute_dtype = a.dtype
 anchors = gi.TRAIN_CASE["anchors"]
 grids = [a.size // 32, a.size // 16, a.size // 8]
 sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(dev)
@@ -49,4 +51,4 @@ for _ in range(a.steps):
 dt = (time.perf_counter() - t0) / a.steps
 import numpy as np
 t = np.mean(np.array(t), 0)
-print(f"B={a.batch} S={a.size} nc={a.classes}: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} img/s | fwd {t[0]:.1f} loss {t[1]:.1f} bwd {t[2]:.1f} sgd {t[3]:.1f} ms | loss {l:.3f}")
+print(f"{a.dtype} B={a.batch} S={a.size} nc={a.classes}: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} img/s | fwd {t[0]:.1f} loss {t[1]:.1f} bwd {t[2]:.1f} sgd {t[3]:.1f} ms | loss {l:.3f}")

@@ -21,8 +21,6 @@
 
 namespace yolo {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ float act_fwd(float u, int act) {
     if (act == YOLO_ACT_LEAKY) return u > 0.f ? u : u * 0.1f;
     if (act == YOLO_ACT_MISH) {
@@ -55,7 +53,8 @@ __device__ __forceinline__ RedGeom red_geom(int c4) {
 }
 
 // partial[blk][c][2] (double): sum z, sum z^2 over the block's pixel range
-__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ z, int m, int c, int ld, int off,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S* __restrict__ z, int m, int c, int ld, int off,
                                                         int pix_per_block, double* __restrict__ partial) {
     __shared__ double red[256][2];
     const int c4 = c >> 2;
@@ -70,14 +69,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
         if (vch < c4 && lane < g.lanes) {
             float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
             int run = 0;
-            const float* zp = z + off + vch * 4;
+            const typename Elt<T>::S* zp = z + off + vch * 4;
             int p = p0 + lane;
             // 4 independent 16-byte loads in flight per thread (one-at-a-time left the kernel at ~45 % of
             // the achievable HBM rate: latency-bound, not bandwidth-bound)
             for (; p + 3 * g.lanes < p1; p += 4 * g.lanes) {
                 f32x4 x[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(zp + (size_t)(p + u * g.lanes) * ld);
+                for (int u = 0; u < 4; ++u) x[u] = Elt<T>::ld4(zp + (size_t)(p + u * g.lanes) * ld);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
                 }
             }
             for (; p < p1; p += g.lanes) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(zp + (size_t)p * ld);
+                const f32x4 x = Elt<T>::ld4(zp + (size_t)p * ld);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { fs[e] += x[e]; fq[e] += x[e] * x[e]; }
             }
@@ -166,11 +165,12 @@ __global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, 
 }
 
 // y = act(z*scale + shift) [+ residual], float4 per thread, same output modes as the conv epilogue
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, int z_ld, int z_off,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ res, int r_ld, int r_off,
-                                                         float* __restrict__ y, int y_ld, int y_off, long long m, int c,
+                                                         const typename Elt<T>::S* __restrict__ res, int r_ld, int r_off,
+                                                         typename Elt<T>::S* __restrict__ y, int y_ld, int y_off, long long m, int c,
                                                          int Ho, int Wo, int act, int out_mode, int* nan_flag) {
     const int c4 = c >> 2;
     const long long total = m * c4;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / c4;
         const int ch = (int)(i - p * c4) * 4;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + ch);
+        const f32x4 x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + ch);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
         f32x4 mu = {0.f, 0.f, 0.f, 0.f};
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fwd((x[e] - mu[e]) * sc[e] + sh[e], act);
-        if (res) v += *reinterpret_cast<const f32x4*>(res + (size_t)p * r_ld + r_off + ch);
+        if (res) v += Elt<T>::ld4(res + (size_t)p * r_ld + r_off + ch);
         bad |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
         if (out_mode == YOLO_OUT_UPSAMPLE2X) {
             const long long hw = (long long)Ho * Wo;
@@ -194,21 +194,22 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
             const int rem = (int)(p - img * hw);
             const int ho = rem / Wo, wo = rem - ho * Wo;
             const int W2 = 2 * Wo;
-            float* d = y + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * y_ld + y_off + ch;
-            *reinterpret_cast<f32x4*>(d) = v;
-            *reinterpret_cast<f32x4*>(d + y_ld) = v;
-            *reinterpret_cast<f32x4*>(d + (size_t)W2 * y_ld) = v;
-            *reinterpret_cast<f32x4*>(d + (size_t)(W2 + 1) * y_ld) = v;
+            typename Elt<T>::S* d = y + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * y_ld + y_off + ch;
+            Elt<T>::st4(d, v);
+            Elt<T>::st4(d + y_ld, v);
+            Elt<T>::st4(d + (size_t)W2 * y_ld, v);
+            Elt<T>::st4(d + (size_t)(W2 + 1) * y_ld, v);
         } else {
-            *reinterpret_cast<f32x4*>(y + (size_t)p * y_ld + y_off + ch) = v;
+            Elt<T>::st4(y + (size_t)p * y_ld + y_off + ch, v);
         }
     }
     if (bad && nan_flag) atomicOr(nan_flag, 2);
 }
 
 // partial[blk][c][2]: sum du, sum du*zhat.  gamma == nullptr: bare conv (du = dy, only sum du is used)
-__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dy, int dy_ld, int dy_off,
-                                                      const float* __restrict__ z, int z_ld, int z_off,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
+                                                      const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       int m, int c, int act, int pix_per_block, double* __restrict__ partial) {
@@ -242,12 +243,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             };
             int p = p0 + lane;
             for (; p + g.lanes < p1; p += 2 * g.lanes) {          // 4 loads in flight (2 pixels x {dy, z})
-                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + vch * 4);
-                const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + (size_t)(p + g.lanes) * dy_ld + dy_off + vch * 4);
+                const f32x4 d0 = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + vch * 4);
+                const f32x4 d1 = Elt<T>::ld4(dy + (size_t)(p + g.lanes) * dy_ld + dy_off + vch * 4);
                 f32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
                 if (mean) {
-                    x0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + vch * 4);
-                    x1 = *reinterpret_cast<const f32x4*>(z + (size_t)(p + g.lanes) * z_ld + z_off + vch * 4);
+                    x0 = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + vch * 4);
+                    x1 = Elt<T>::ld4(z + (size_t)(p + g.lanes) * z_ld + z_off + vch * 4);
                 }
                 accum(d0, x0);
                 accum(d1, x1);
@@ -259,9 +260,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                 }
             }
             for (; p < p1; p += g.lanes) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + vch * 4);
+                const f32x4 d = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + vch * 4);
                 f32x4 x = {0, 0, 0, 0};
-                if (mean) x = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + vch * 4);
+                if (mean) x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + vch * 4);
                 accum(d, x);
             }
 #pragma unroll
@@ -300,19 +301,20 @@ __global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, in
     coef[ch * 3 + 2] = (float)(q / m);                  // mean(du * zhat)
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, int dy_ld, int dy_off,
-                                                    const float* __restrict__ z, int z_ld, int z_off,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
+                                                    const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    const float* __restrict__ coef, float* __restrict__ dz, int dz_ld,
+                                                    const float* __restrict__ coef, typename Elt<T>::S* __restrict__ dz, int dz_ld,
                                                     int dz_off, long long m, int c, int act) {
     const int c4 = c >> 2;
     const long long total = m * c4;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / c4;
         const int ch = (int)(i - p * c4) * 4;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + dy_off + ch);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(z + (size_t)p * z_ld + z_off + ch);
+        const f32x4 d = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + ch);
+        const f32x4 x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + ch);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch);
@@ -324,13 +326,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
             const float du = d[e] * act_grad(xc * sc[e] + sh[e], act);
             o[e] = coef[(ch + e) * 3] * (du - coef[(ch + e) * 3 + 1] - xc * is[e] * coef[(ch + e) * 3 + 2]);
         }
-        *reinterpret_cast<f32x4*>(dz + (size_t)p * dz_ld + dz_off + ch) = o;
+        Elt<T>::st4(dz + (size_t)p * dz_ld + dz_off + ch, o);
     }
 }
 
 // gradient of nn.Upsample(scale_factor=2, nearest): each source pixel sums its 2x2 destinations
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dup, int d_ld, int d_off,
-                                                             float* __restrict__ dx, int x_ld, int x_off, long long m,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const typename Elt<T>::S* __restrict__ dup, int d_ld, int d_off,
+                                                             typename Elt<T>::S* __restrict__ dx, int x_ld, int x_off, long long m,
                                                              int c, int Ho, int Wo) {
     const int c4 = c >> 2;
     const long long total = m * c4;
@@ -342,12 +345,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         const int rem = (int)(p - img * hw);
         const int ho = rem / Wo, wo = rem - ho * Wo;
         const int W2 = 2 * Wo;
-        const float* s = dup + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * d_ld + d_off + ch;
-        f32x4 v = *reinterpret_cast<const f32x4*>(s);
-        v += *reinterpret_cast<const f32x4*>(s + d_ld);
-        v += *reinterpret_cast<const f32x4*>(s + (size_t)W2 * d_ld);
-        v += *reinterpret_cast<const f32x4*>(s + (size_t)(W2 + 1) * d_ld);
-        *reinterpret_cast<f32x4*>(dx + (size_t)p * x_ld + x_off + ch) = v;
+        const typename Elt<T>::S* s = dup + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * d_ld + d_off + ch;
+        f32x4 v = Elt<T>::ld4(s);
+        v += Elt<T>::ld4(s + d_ld);
+        v += Elt<T>::ld4(s + (size_t)W2 * d_ld);
+        v += Elt<T>::ld4(s + (size_t)(W2 + 1) * d_ld);
+        Elt<T>::st4(dx + (size_t)p * x_ld + x_off + ch, v);
     }
 }
 
@@ -377,16 +380,17 @@ size_t yolo_bn_workspace_bytes(int m, int c) {
     return (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 3 * sizeof(float);
 }
 
-int yolo_bn_stats(const float* z, int m, int c, int ld, int off, const float* gamma, const float* beta, float momentum,
+int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gamma, const float* beta, float momentum,
                   float eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                  float* shift, void* workspace, size_t workspace_bytes, void* stream) {
+                  float* shift, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!z || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace) return fail(YOLO_ERR_ARG, "bn_stats: null pointer");
     if (m <= 0 || c <= 0 || (c & 3) || (ld & 3) || (off & 3) || ld < c) return fail(YOLO_ERR_ARG, "bn_stats: c/ld/off must be multiples of 4");
     if (workspace_bytes < yolo_bn_workspace_bytes(m, c)) return fail(YOLO_ERR_WORKSPACE, "bn_stats: workspace too small");
     int ppb;
     const int nblk = red_blocks(m, &ppb);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, s, z, m, c, ld, off, ppb, (double*)workspace);
+    YOLO_DISPATCH_DTYPE(dtype, "bn_stats",
+        hipLaunchKernelGGL(bn_stats_partial<T>, dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)z, m, c, ld, off, ppb, (double*)workspace));
     int rc = check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, (const double*)workspace, nblk, m, c, momentum,
@@ -394,22 +398,24 @@ int yolo_bn_stats(const float* z, int m, int c, int ld, int off, const float* ga
     return check_launch("bn_stats_finalize");
 }
 
-int yolo_bn_act_fwd(const float* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const float* residual,
-                    int r_ld, int r_off, float* y, int y_ld, int y_off, int n, int h, int w, int c, int act, int out_mode,
-                    int32_t* nan_flag, void* stream) {
+int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const void* residual,
+                    int r_ld, int r_off, void* y, int y_ld, int y_off, int n, int h, int w, int c, int act, int out_mode,
+                    int dtype, int32_t* nan_flag, void* stream) {
     if (!z || !scale || !shift || !y) return fail(YOLO_ERR_ARG, "bn_act_fwd: null pointer");
     if ((c & 3) || (z_ld & 3) || (z_off & 3) || (y_ld & 3) || (y_off & 3) || (residual && ((r_ld & 3) || (r_off & 3))))
         return fail(YOLO_ERR_ARG, "bn_act_fwd: channel counts / strides must be multiples of 4");
     if (out_mode != YOLO_OUT_NHWC && out_mode != YOLO_OUT_UPSAMPLE2X) return fail(YOLO_ERR_ARG, "bn_act_fwd: out_mode");
     const long long m = (long long)n * h * w;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, z, z_ld, z_off, mean, scale, shift,
-                       residual, r_ld, r_off, y, y_ld, y_off, m, c, h, w, act, out_mode, nan_flag);
+    YOLO_DISPATCH_DTYPE(dtype, "bn_act_fwd",
+        hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z, z_ld,
+                           z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, m, c, h, w, act,
+                           out_mode, nan_flag));
     return check_launch("bn_act_fwd");
 }
 
-int yolo_bn_act_bwd(const float* dy, int dy_ld, int dy_off, const float* z, int z_ld, int z_off, const float* gamma,
+int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_ld, int z_off, const float* gamma,
                     const float* mean, const float* invstd, const float* scale, const float* shift, int m, int c, int act,
-                    float* dgamma, float* dbeta, float* dz, int dz_ld, int dz_off, void* workspace, size_t workspace_bytes,
+                    float* dgamma, float* dbeta, void* dz, int dz_ld, int dz_off, int dtype, void* workspace, size_t workspace_bytes,
                     void* stream) {
     if (!dy || !dbeta || !workspace) return fail(YOLO_ERR_ARG, "bn_act_bwd: null pointer");
     if (gamma && (!z || !mean || !invstd || !scale || !shift || !dgamma || !dz)) return fail(YOLO_ERR_ARG, "bn_act_bwd: null pointer");
@@ -420,24 +426,27 @@ int yolo_bn_act_bwd(const float* dy, int dy_ld, int dy_off, const float* z, int 
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)nblk * c * 2 * sizeof(double));
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk), dim3(256), 0, s, dy, dy_ld, dy_off, z, z_ld, z_off, gamma ? mean : nullptr, invstd,
-                       scale, shift, m, c, act, ppb, part);
+    YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
+        hipLaunchKernelGGL(bn_bwd_partial<T>, dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld, z_off,
+                           gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part));
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
     rc = check_launch("bn_bwd_finalize");
     if (rc || !gamma) return rc;
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid((long long)m * (c / 4))), dim3(256), 0, s, dy, dy_ld, dy_off, z, z_ld, z_off, mean, invstd, scale, shift,
-                       coef, dz, dz_ld, dz_off, (long long)m, c, act);
+    YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
+        hipLaunchKernelGGL(bn_bwd_apply<T>, dim3(ew_grid((long long)m * (c / 4))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                           (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, (long long)m, c, act));
     return check_launch("bn_bwd_apply");
 }
 
-int yolo_upsample2x_bwd(const float* dup, int d_ld, int d_off, float* dx, int x_ld, int x_off, int n, int h, int w, int c,
-                        void* stream) {
+int yolo_upsample2x_bwd(const void* dup, int d_ld, int d_off, void* dx, int x_ld, int x_off, int n, int h, int w, int c,
+                        int dtype, void* stream) {
     if (!dup || !dx || (c & 3) || (d_ld & 3) || (d_off & 3) || (x_ld & 3) || (x_off & 3)) return fail(YOLO_ERR_ARG, "upsample2x_bwd: bad arguments");
     const long long m = (long long)n * h * w;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, dup, d_ld, d_off, dx, x_ld,
-                       x_off, m, c, h, w);
+    YOLO_DISPATCH_DTYPE(dtype, "upsample2x_bwd",
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)dup, d_ld,
+                           d_off, (Elt<T>::S*)dx, x_ld, x_off, m, c, h, w));
     return check_launch("upsample2x_bwd");
 }
 

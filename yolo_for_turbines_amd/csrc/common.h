@@ -26,6 +26,60 @@ inline int kpad_of(int cin, int ks) { return round_up(ks * ks * cin_pad_of(cin),
 inline int coutpad_of(int cout) { return round_up(cout, 128); }
 
 
+// ---- element types of activation / gradient tensors: fp32, or 16-bit storage with fp32 arithmetic.
+// Kernels are templated on T in {float, __bf16, _Float16}; S is the storage type behind the void* of the ABI.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+    typedef float S;
+    static __device__ __forceinline__ f32x4 ld4(const S* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st4(S* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float ld(const S* p) { return *p; }
+    static __device__ __forceinline__ void st(S* p, float v) { *p = v; }
+};
+template <> struct Elt<__bf16> {
+    typedef unsigned short S;
+    static __device__ __forceinline__ f32x4 ld4(const S* p) {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+        f32x4 v = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                   __uint_as_float(r[1] & 0xffff0000u)};
+        return v;
+    }
+    static __device__ __forceinline__ unsigned short cvt(float f) { __bf16 h = (__bf16)f; return *reinterpret_cast<unsigned short*>(&h); }
+    static __device__ __forceinline__ void st4(S* p, f32x4 v) {
+        u32x2 r = {(unsigned)cvt(v[0]) | ((unsigned)cvt(v[1]) << 16), (unsigned)cvt(v[2]) | ((unsigned)cvt(v[3]) << 16)};
+        *reinterpret_cast<u32x2*>(p) = r;
+    }
+    static __device__ __forceinline__ float ld(const S* p) { return __uint_as_float((unsigned)*p << 16); }
+    static __device__ __forceinline__ void st(S* p, float v) { *p = cvt(v); }
+};
+template <> struct Elt<_Float16> {
+    typedef unsigned short S;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld4(const S* p) {
+        const h4 h = *reinterpret_cast<const h4*>(p);
+        f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        return v;
+    }
+    static __device__ __forceinline__ void st4(S* p, f32x4 v) {
+        h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<h4*>(p) = h;
+    }
+    static __device__ __forceinline__ float ld(const S* p) { return (float)*reinterpret_cast<const _Float16*>(p); }
+    static __device__ __forceinline__ void st(S* p, float v) { *reinterpret_cast<_Float16*>(p) = (_Float16)v; }
+};
+
+// run `body` with T bound to the element type of `dtype` (host side)
+#define YOLO_DISPATCH_DTYPE(dtype, what, ...)                                             \
+    switch (dtype) {                                                                      \
+    case YOLO_F32: { typedef float T; __VA_ARGS__; } break;                               \
+    case YOLO_BF16: { typedef __bf16 T; __VA_ARGS__; } break;                             \
+    case YOLO_F16: { typedef _Float16 T; __VA_ARGS__; } break;                            \
+    default: return fail(YOLO_ERR_ARG, "%s: unknown dtype %d", what, (int)(dtype));       \
+    }
+
 // conv_f32_v2.hip ("patch + fragment stream" kernel, stride 1, cin % 32 == 0)
 bool v2_eligible(const yolo_conv_desc* d);
 size_t v2_frag_elems(int cout, int cin, int ks);
@@ -36,6 +90,7 @@ int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, cons
 // conv_h16.hip (bf16 / fp16 patch kernel)
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
+int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s);
 // offset (elements) of the fragment-order copy inside a packed weight buffer

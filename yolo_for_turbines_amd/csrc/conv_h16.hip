@@ -22,7 +22,6 @@
 namespace yolo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -455,6 +454,27 @@ __global__ void pack_weights_frag_h16(const float* __restrict__ w, unsigned shor
     }
 }
 
+// same fragment order for the stride-1 input-gradient convolution dx = conv(dz, W'):
+// n = ci, k channel = co, W'[ci][co][tap] = W[co][ci][taps-1-tap]  (see dgrad_f32.hip)
+template <typename T>
+__global__ void pack_dgrad_frag_h16(const float* __restrict__ w, unsigned short* __restrict__ wf, int cout, int cin, int ks,
+                                    int KT, long long total) {
+    const int taps = ks * ks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const int s = (int)((i >> 9) & 1);
+        const long long rest = i >> 10;
+        const int kt = (int)(rest % KT);
+        const int nt = (int)(rest / KT);
+        const int ci = nt * 32 + (lane & 31);
+        const int chunk = kt / taps, tap = kt - chunk * taps;
+        const int co = chunk * 32 + s * 16 + 8 * (lane >> 5) + e;
+        const float v = (ci < cin && co < cout) ? w[((size_t)co * cin + ci) * taps + (taps - 1 - tap)] : 0.f;
+        wf[i] = HTraits<T>::from_f32(v);
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
 
@@ -472,6 +492,18 @@ int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype
     else
         hipLaunchKernelGGL(pack_weights_frag_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ks, KT, total);
     return check_launch("pack_weights_frag_h16");
+}
+
+int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s) {
+    const int coutp = round_up(cout, 32);
+    const long long total = (long long)h16_frag_elems(cin, coutp, ks);
+    const int KT = (coutp / 32) * ks * ks;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL(pack_dgrad_frag_h16<__bf16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ks, KT, total);
+    else
+        hipLaunchKernelGGL(pack_dgrad_frag_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ks, KT, total);
+    return check_launch("pack_dgrad_frag_h16");
 }
 
 static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax) {

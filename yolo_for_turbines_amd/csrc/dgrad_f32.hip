@@ -21,13 +21,12 @@
 namespace yolo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct DgradS2Args {
-    const float* dz;      // (N, Ho, Wo, Cout) gradient of the raw conv output
-    const float* w;       // [Cin_pad128][9*Cout] : W'[ci][tap*Cout + co] = W[co][ci][tap]
-    const float* res;     // optional other contribution to dx (same geometry as dx)
-    float* dx;            // (N, 2Ho, 2Wo, Cin)
+    const void* dz;       // (N, Ho, Wo, Cout) gradient of the raw conv output          (element type T)
+    const float* w;       // [Cin_pad128][9*Cout] : W'[ci][tap*Cout + co] = W[co][ci][tap]   (fp32)
+    const void* res;      // optional other contribution to dx (same geometry as dx)      (T)
+    void* dx;             // (N, 2Ho, 2Wo, Cin)                                            (T)
     int N, Ho, Wo, Cin, Cout;
     int dz_ld, dz_off, dx_ld, dx_off, r_ld, r_off;
     int Mc;               // pixels per class = N*Ho*Wo
@@ -36,7 +35,12 @@ struct DgradS2Args {
 
 constexpr int DLD = 36;
 
+template <typename T>
 __global__ __launch_bounds__(256) void dgrad_s2_f32_kernel(const DgradS2Args p) {
+    typedef typename Elt<T>::S S;
+    const S* gz = reinterpret_cast<const S*>(p.dz);
+    const S* gres = reinterpret_cast<const S*>(p.res);
+    S* gdx = reinterpret_cast<S*>(p.dx);
     constexpr int BM = 64, BN = 64;
     __shared__ __attribute__((aligned(16))) float As[2][BM][DLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][DLD];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_f32_kernel(const DgradS2Args p) 
         for (int i = 0; i < 2; ++i) {
             const bool v = a_ok[i] && a_r[i] + dh < p.Ho && a_c[i] + dw < p.Wo;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = v ? *reinterpret_cast<const f32x4*>(p.dz + a_base[i] + toff) : z;
+            ra[i] = v ? Elt<T>::ld4(gz + a_base[i] + toff) : z;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(256) void dgrad_s2_f32_kernel(const DgradS2Args p) 
         const int rr = rem / p.Wo, cc = rem - rr * p.Wo;
         const size_t pix = (size_t)(img * H2 + 2 * rr + ph) * W2 + 2 * cc + pw;
         float v = acc[r];
-        if (p.res) v += p.res[pix * p.r_ld + p.r_off + n];
-        p.dx[pix * p.dx_ld + p.dx_off + n] = v;
+        if (gres) v += Elt<T>::ld(gres + pix * p.r_ld + p.r_off + n);
+        Elt<T>::st(gdx + pix * p.dx_ld + p.dx_off + n, v);
     }
 }
 
@@ -176,8 +180,9 @@ __global__ void pack_dgrad_frag(const float* __restrict__ w, float* __restrict__
 }
 
 // (B,3,g,g,D) head-layout gradient -> NHWC (B,g,g,ld) with channel a*D+k, pad channels zeroed
+template <typename T>
 __global__ void head_grad_to_nhwc_kernel(const float* __restrict__ dp, long long sb, long long sa, long long sy, long long sx,
-                                         long long sk, float* __restrict__ out, int B, int g, int D, int ld) {
+                                         long long sk, typename Elt<T>::S* __restrict__ out, int B, int g, int D, int ld) {
     const long long total = (long long)B * g * g * ld;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ch = (int)(i % ld);
@@ -190,7 +195,7 @@ __global__ void head_grad_to_nhwc_kernel(const float* __restrict__ dp, long long
             const int a = ch / D, k = ch - a * D;
             v = dp[b * sb + a * sa + y * sy + x * sx + k * sk];
         }
-        out[i] = v;
+        Elt<T>::st(out + i, v);
     }
 }
 
@@ -202,14 +207,16 @@ extern "C" {
 
 /* packed size of the gradient-convolution weights of a conv (cout, cin, k): row-major part + (k-flipped)
  * fragment-order part; the latter only exists for flip = 1 layouts and cout rounded up to 32. */
-size_t yolo_packed_dgrad_elems(int cout, int cin, int ksize) {
+size_t yolo_packed_dgrad_bytes(int cout, int cin, int ksize, int flip, int dtype) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const int coutp = round_up(cout, 32);
-    return v0_packed_elems(cin, coutp, ksize) + v2_frag_elems(cin, coutp, ksize);
+    if (flip && dtype != YOLO_F32) return h16_frag_elems(cin, coutp, ksize) * 2;
+    return (v0_packed_elems(cin, coutp, ksize) + v2_frag_elems(cin, coutp, ksize)) * sizeof(float);
 }
 
-int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, void* stream) {
-    if (!w_oihw || !w_packed || !yolo_packed_dgrad_elems(cout, cin, ksize)) return fail(YOLO_ERR_ARG, "pack_weights_dgrad: bad arguments");
+int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, int dtype, void* stream) {
+    if (!w_oihw || !w_packed || !yolo_packed_dgrad_bytes(cout, cin, ksize, flip, dtype)) return fail(YOLO_ERR_ARG, "pack_weights_dgrad: bad arguments");
+    if (flip && dtype != YOLO_F32) return h16_pack_dgrad(w_oihw, w_packed, cout, cin, ksize, dtype, (hipStream_t)stream);
     const int coutp = round_up(cout, 32);
     const int kpad = kpad_of(coutp, ksize);
     const long long total = (long long)v0_packed_elems(cin, coutp, ksize);
@@ -227,8 +234,8 @@ int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int c
 
 /* dx (N,2Ho,2Wo,cin) = transposed 3x3 stride-2 conv of dz (N,Ho,Wo,cout) [+ residual]; w_packed from
  * yolo_pack_weights_dgrad(flip = 0). cout % 32 == 0. */
-int yolo_conv_dgrad_s2(const float* dz, int dz_ld, int dz_off, const void* w_packed, const float* residual, int r_ld, int r_off,
-                       float* dx, int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, void* stream) {
+int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_packed, const void* residual, int r_ld, int r_off,
+                       void* dx, int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, void* stream) {
     if (!dz || !w_packed || !dx) return fail(YOLO_ERR_ARG, "dgrad_s2: null pointer");
     if (n <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0 || cout % 32) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2: cout %% 32 != 0");
     if ((dz_ld & 3) || (dz_off & 3)) return fail(YOLO_ERR_ARG, "dgrad_s2: dz_ld/dz_off must be multiples of 4");
@@ -242,16 +249,19 @@ int yolo_conv_dgrad_s2(const float* dz, int dz_ld, int dz_off, const void* w_pac
     a.tiles_per_class = ceil_div(a.Mc, 64);
     a.tiles_n = ceil_div(cin, 64);
     a.Kpad = kpad_of(cout, 3);
-    hipLaunchKernelGGL(dgrad_s2_f32_kernel, dim3(4 * a.tiles_per_class * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
+    YOLO_DISPATCH_DTYPE(dtype, "dgrad_s2",
+        hipLaunchKernelGGL(dgrad_s2_f32_kernel<T>, dim3(4 * a.tiles_per_class * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a));
     return check_launch("dgrad_s2_f32");
 }
 
-int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, float* out, int b, int g, int d, int ld, void* stream) {
+int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream) {
     if (!dp || !strides5 || !out || b <= 0 || g <= 0 || d <= 0 || ld < 3 * d) return fail(YOLO_ERR_ARG, "head_grad_to_nhwc: bad arguments");
     const long long total = (long long)b * g * g * ld;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(head_grad_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (long long)strides5[0],
-                       (long long)strides5[1], (long long)strides5[2], (long long)strides5[3], (long long)strides5[4], out, b, g, d, ld);
+    YOLO_DISPATCH_DTYPE(dtype, "head_grad_to_nhwc",
+        hipLaunchKernelGGL(head_grad_to_nhwc_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (long long)strides5[0],
+                           (long long)strides5[1], (long long)strides5[2], (long long)strides5[3], (long long)strides5[4], (Elt<T>::S*)out,
+                           b, g, d, ld));
     return check_launch("head_grad_to_nhwc");
 }
 

@@ -15,11 +15,10 @@
 namespace yolo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
-    const float* dz;
-    const float* x;
+    const void* dz;         // element type T of the kernel template
+    const void* x;
     float* partial;
     int N, H, W, Ho, Wo, M;
     int Cin, Cout;          // Cin = padded to 4
@@ -33,8 +32,11 @@ struct WgradArgs {
 
 constexpr int WBK = 32;     // pixels per K step
 
-template <int BM, int BN, bool SMALLC>
+template <typename T, int BM, int BN, bool SMALLC>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs p) {
+    typedef typename Elt<T>::S S;
+    const S* gz = reinterpret_cast<const S*>(p.dz);
+    const S* gx = reinterpret_cast<const S*>(p.x);
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A4 = BM / 4, B4 = BN / 4;                   // float4 columns
     constexpr int AR = 256 / A4, BR = 256 / B4;               // rows per pass
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs p) {
             const int pix = p0 + a_r + i * AR;
             const int co = co0 + a_c4 * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = (pix < p.M && co < co_lim) ? *reinterpret_cast<const f32x4*>(p.dz + (size_t)pix * p.dz_ld + p.dz_off + co) : z;
+            ra[i] = (pix < p.M && co < co_lim) ? Elt<T>::ld4(gz + (size_t)pix * p.dz_ld + p.dz_off + co) : z;
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs p) {
                 if (SMALLC) { t = b_c4; ci = 0; th = t / p.ks; tw = t - th * p.ks; }     // one 4-channel tap per float4 column
                 const int hi = ho * p.stride + th - p.pad, wi = wo * p.stride + tw - p.pad;
                 if (t < p.ks * p.ks && ci < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    rb[i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.H + hi) * p.W + wi) * p.x_ld + p.x_off + ci);
+                    rb[i] = Elt<T>::ld4(gx + ((size_t)(n * p.H + hi) * p.W + wi) * p.x_ld + p.x_off + ci);
             }
         }
     };
@@ -192,7 +194,8 @@ using namespace yolo;
 
 extern "C" {
 
-size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride) {
+size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride, int dtype) {
+    if (dtype != YOLO_F32 && dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     const WgradPlan q = plan_wgrad(n, h, w, cin, cout, ksize, stride);
     return (size_t)q.nslices * q.cout_pad * q.kp * sizeof(float);
@@ -200,10 +203,10 @@ size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ks
 
 /* dz: NHWC gradient of the raw conv output (n, ho, wo, cout) with channel stride dz_ld (>= cout rounded
  * up to 4; any padding channels must be zero); x: NHWC conv input; dw: OIHW fp32 out. */
-int yolo_conv_wgrad(const float* dz, int dz_ld, int dz_off, const float* x, int x_ld, int x_off, float* dw_oihw, int n, int h,
-                    int w, int cin, int cout, int ksize, int stride, void* workspace, size_t workspace_bytes, void* stream) {
+int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* dw_oihw, int n, int h,
+                    int w, int cin, int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dz || !x || !dw_oihw || !workspace) return fail(YOLO_ERR_ARG, "wgrad: null pointer");
-    const size_t need = yolo_wgrad_workspace_bytes(n, h, w, cin, cout, ksize, stride);
+    const size_t need = yolo_wgrad_workspace_bytes(n, h, w, cin, cout, ksize, stride, dtype);
     if (!need) return fail(YOLO_ERR_ARG, "wgrad: bad shape");
     if (workspace_bytes < need) return fail(YOLO_ERR_WORKSPACE, "wgrad: workspace %zu < %zu", workspace_bytes, need);
     const int cp = cin_pad_of(cin);
@@ -222,13 +225,14 @@ int yolo_conv_wgrad(const float* dz, int dz_ld, int dz_off, const float* x, int 
     a.tiles_n = q.tiles_n; a.tiles_per_tap = q.tiles_per_tap; a.cout_pad = q.cout_pad;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(q.tiles_m * q.tiles_n, q.nslices), block(256);
-    if (q.smallc) {
-        if (q.bm == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, true>), grid, block, 0, s, a);
-    } else if (q.bm == 128 && q.bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, false>), grid, block, 0, s, a);
-    else if (q.bm == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64, false>), grid, block, 0, s, a);
-    else if (q.bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, false>), grid, block, 0, s, a);
+    YOLO_DISPATCH_DTYPE(dtype, "wgrad",
+        if (q.smallc) {
+            if (q.bm == 128) hipLaunchKernelGGL((wgrad_f32_kernel<T, 128, 64, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<T, 64, 64, true>), grid, block, 0, s, a);
+        } else if (q.bm == 128 && q.bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<T, 128, 128, false>), grid, block, 0, s, a);
+        else if (q.bm == 128) hipLaunchKernelGGL((wgrad_f32_kernel<T, 128, 64, false>), grid, block, 0, s, a);
+        else if (q.bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<T, 64, 128, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_f32_kernel<T, 64, 64, false>), grid, block, 0, s, a));
     int rc = check_launch("wgrad_f32");
     if (rc) return rc;
     const long long total = (long long)cout * cin * ksize * ksize;

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import PackedBlock, Program, TView, _act_code, build_network_program
+from .engine import _DT, PackedBlock, Program, TView, _act_code, build_network_program, resolve_dtype
 
 _const_cache = {}
 
@@ -34,9 +34,9 @@ def _consts(device, n=2048):
     return c
 
 
-def _desc(B, x: TView, cin, cout, k, s, y_ld, y_off, r: TView = None, act=L.ACT_NONE, out_mode=L.OUT_NHWC, flags=0):
+def _desc(B, x: TView, cin, cout, k, s, y_ld, y_off, r: TView = None, act=L.ACT_NONE, out_mode=L.OUT_NHWC, flags=0, dtype=L.F32):
     d = L.ConvDesc(n=B, h=x.H, w=x.W, cin=cin, cout=cout, ksize=k, stride=s, x_ld=x.ld, x_off=x.off, y_ld=y_ld,
-                   y_off=y_off, act=act, out_mode=out_mode, dtype=L.F32, flags=flags, tile=0)
+                   y_off=y_off, act=act, out_mode=out_mode, dtype=dtype, flags=flags, tile=0)
     if r is not None:
         d.r_ld, d.r_off = r.ld, r.off
         d.flags |= L.FLAG_RESIDUAL
@@ -44,12 +44,20 @@ def _desc(B, x: TView, cin, cout, k, s, y_ld, y_off, r: TView = None, act=L.ACT_
 
 
 class TrainPlan:
-    """Buffers for one (batch, size): activations y, raw conv outputs z, per-block statistics."""
+    """Buffers for one (batch, size, dtype): activations y, raw conv outputs z (both in the compute
+    dtype), per-block statistics (fp32)."""
 
-    def __init__(self, prog: Program, device):
+    def __init__(self, prog: Program, device, dtype="fp32"):
         self.prog, self.device, self.B = prog, device, prog.B
+        self.dtype = dtype
+        self.code, self.tdtype = _DT[dtype]
         f32 = dict(dtype=torch.float32, device=device)
-        self.ybuf = [torch.empty(n, **f32) for n in prog.buf_numel]
+        act = dict(dtype=self.tdtype, device=device)
+        self.ybuf = [torch.empty(n, **act) for n in prog.buf_numel]
+        # 16-bit: the 3-channel first block has no matrix-core kernel; it runs on the stem kernel
+        op0 = prog.ops[0] if prog.ops else None
+        self.stem = (dtype != "fp32" and op0 is not None and op0["x"].buf == prog.input.buf and
+                     bool(L.lib().yolo_stem_supported(op0["block"].conv.in_channels, op0["block"].conv.out_channels, op0["k"], op0["s"])))
         self.z, self.stats = [], []
         max_bn, max_wg = 256, 256
         lib = L.lib()
@@ -57,7 +65,7 @@ class TrainPlan:
             blk, cv = op["block"], op["block"].conv
             m = self.B * op["Ho"] * op["Wo"]
             if blk.batch_norm_act:
-                self.z.append(torch.empty(m * cv.out_channels, **f32))
+                self.z.append(torch.empty(m * cv.out_channels, **act))
                 self.stats.append(torch.empty(4, cv.out_channels, **f32))        # mean, invstd, scale, shift
                 max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, cv.out_channels))
             else:
@@ -65,7 +73,7 @@ class TrainPlan:
                 self.stats.append(None)
                 max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, (cv.out_channels + 31) // 32 * 32))
             max_wg = max(max_wg, lib.yolo_wgrad_workspace_bytes(self.B, op["x"].H, op["x"].W, cv.in_channels, cv.out_channels,
-                                                                 op["k"], op["s"]))
+                                                                 op["k"], op["s"], self.code))
         self.bn_ws = torch.empty(max_bn, dtype=torch.uint8, device=device)
         self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
@@ -82,32 +90,37 @@ def _forward(state, model, plan: TrainPlan, x):
     stream = L.current_stream()
     ones, zeros = _consts(dev)
     blocks = [op["block"] for op in prog.ops]
-    state.refresh_weights(blocks, dev, stream)
+    code = plan.code
+    state.refresh_weights(blocks, dev, stream, plan.dtype)
     plan.nan_flag.zero_()
     xin = x.detach()
     if xin.dtype != torch.float32 or not xin.is_contiguous():
         xin = xin.float().contiguous()
     inp = prog.input
     L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.ybuf[inp.buf].data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], inp.ld,
-                                  L.F32, plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
+                                  code, plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
     preds = [None] * prog.n_pred
     for i, op in enumerate(prog.ops):
         blk, cv = op["block"], op["block"].conv
-        pk = state.packed(blk, dev)
+        pk = state.packed(blk, dev, plan.dtype)
         xv, yv, rv = op["x"], op["y"], op["res"]
         cout = cv.out_channels
         if not blk.batch_norm_act:                       # bare conv + bias (heads): single fused launch
             g = op["Ho"]
             out = torch.empty((B, 3, g, g, cout // 3), dtype=torch.float32, device=dev)
-            d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], 0, 0, act=L.ACT_NONE, out_mode=op["out_mode"])
+            d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], 0, 0, act=L.ACT_NONE, out_mode=op["out_mode"], dtype=code)
             L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), pk.scale.data_ptr(), pk.shift.data_ptr(), 0,
                                       out.data_ptr(), plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(head)")
             preds[op["pred"]] = out
             continue
         z = plan.z[i]
-        d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0)
-        L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
-                                  plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(raw)")
+        if i == 0 and plan.stem:
+            L.check(lib.yolo_stem_fwd(xin.data_ptr(), pk.stem_w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), z.data_ptr(), B,
+                                      xv.H, xv.W, cout, cout, 0, L.ACT_NONE, code, plan.nan_flag.data_ptr(), stream), "yolo_stem_fwd(raw)")
+        else:
+            d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0, dtype=code)
+            L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
+                                      plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(raw)")
         bn = blk.batch_norm
         st = plan.stats[i]
         m = B * op["Ho"] * op["Wo"]
@@ -115,7 +128,7 @@ def _forward(state, model, plan: TrainPlan, x):
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         L.check(lib.yolo_bn_stats(z.data_ptr(), m, cout, cout, 0, bn.weight.data_ptr(), bn.bias.data_ptr(), mom, float(bn.eps),
                                   bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
-                                  st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                  st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), code,
                                   plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
         if track:
             bn.num_batches_tracked += 1
@@ -123,7 +136,7 @@ def _forward(state, model, plan: TrainPlan, x):
         L.check(lib.yolo_bn_act_fwd(z.data_ptr(), cout, 0, st[0].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
                                     plan.view_ptr(rv) if rv is not None else 0, rv.ld if rv is not None else 0,
                                     rv.off if rv is not None else 0, plan.view_ptr(yv), yv.ld, yv.off, B, op["Ho"], op["Wo"],
-                                    cout, _act_code(blk), op["out_mode"], flag_ptr, stream), "yolo_bn_act_fwd")
+                                    cout, _act_code(blk), op["out_mode"], code, flag_ptr, stream), "yolo_bn_act_fwd")
     return preds
 
 
@@ -139,7 +152,7 @@ class _Grads:
         free = self.pool.get(numel)
         if free:
             return free.pop()
-        return torch.empty(numel, dtype=torch.float32, device=self.plan.device)
+        return torch.empty(numel, dtype=self.plan.tdtype, device=self.plan.device)
 
     def release(self, buf):
         st = self.state.pop(buf, None)
@@ -163,7 +176,7 @@ class _Grads:
         ones, zeros = _consts(self.plan.device)
         B = self.plan.B
         L.check(L.lib().yolo_bn_act_fwd(ptr, ld, off, 0, ones.data_ptr(), zeros.data_ptr(), own.data_ptr(), v.ld, v.off,
-                                        own.data_ptr(), v.ld, v.off, B, v.H, v.W, v.C, L.ACT_NONE, L.OUT_NHWC, 0,
+                                        own.data_ptr(), v.ld, v.off, B, v.H, v.W, v.C, L.ACT_NONE, L.OUT_NHWC, self.plan.code, 0,
                                         L.current_stream()), "grad add")
 
     def _own(self, v: TView):
@@ -201,6 +214,7 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
     prog, B, dev = plan.prog, plan.B, plan.device
     stream = L.current_stream()
     ones, zeros = _consts(dev)
+    code = plan.code
     grads = {}
 
     def new_grad(p, shape=None):
@@ -220,7 +234,7 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
     def scratch(numel):
         t = dz_scratch.get(numel)
         if t is None:
-            t = dz_scratch[numel] = torch.empty(numel, dtype=torch.float32, device=dev)
+            t = dz_scratch[numel] = torch.empty(numel, dtype=plan.tdtype, device=dev)
         return t
 
     for i in range(len(prog.ops) - 1, -1, -1):
@@ -241,12 +255,12 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             else:
                 dp = dp.float()
                 strides = (C.c_int64 * 5)(*dp.stride())
-                L.check(lib.yolo_head_grad_to_nhwc(dp.data_ptr(), strides, dz.data_ptr(), B, Ho, cout // 3, coutp, stream),
+                L.check(lib.yolo_head_grad_to_nhwc(dp.data_ptr(), strides, dz.data_ptr(), B, Ho, cout // 3, coutp, code, stream),
                         "yolo_head_grad_to_nhwc")
             if need.get(id(cv.bias), False):
                 db = torch.empty(coutp, dtype=torch.float32, device=dev)
                 L.check(lib.yolo_bn_act_bwd(dz.data_ptr(), coutp, 0, 0, 0, 0, 0, 0, 0, 0, 0, m, coutp, L.ACT_NONE, 0, db.data_ptr(),
-                                            0, 0, 0, plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "bias grad")
+                                            0, 0, 0, code, plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "bias grad")
                 gb = new_grad(cv.bias)
                 gb.copy_(db[:cout])                          # drop the channel padding (device-side copy)
                 grads[id(cv.bias)] = gb
@@ -255,7 +269,7 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             if op["out_mode"] == L.OUT_UPSAMPLE2X:      # y lives upsampled inside the concat buffer
                 gptr, gld, goff = G.get(yv)
                 dy = scratch(m * cout + 1)              # distinct key from dz of the same size
-                L.check(lib.yolo_upsample2x_bwd(gptr, gld, goff, dy.data_ptr(), cout, 0, B, Ho, Wo, cout, stream), "upsample2x_bwd")
+                L.check(lib.yolo_upsample2x_bwd(gptr, gld, goff, dy.data_ptr(), cout, 0, B, Ho, Wo, cout, code, stream), "upsample2x_bwd")
                 dy_ptr, dy_ld, dy_off = dy.data_ptr(), cout, 0
             else:
                 dy_ptr, dy_ld, dy_off = G.get(yv)
@@ -268,7 +282,7 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             dbeta = new_grad(bn.bias)
             L.check(lib.yolo_bn_act_bwd(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
                                         st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
-                                        dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, plan.bn_ws.data_ptr(),
+                                        dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, code, plan.bn_ws.data_ptr(),
                                         plan.bn_ws.numel(), stream), "yolo_bn_act_bwd")
             grads[id(bn.weight)] = dgamma
             grads[id(bn.bias)] = dbeta
@@ -278,23 +292,23 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
         if need.get(id(cv.weight), False):
             dw = new_grad(cv.weight)
             L.check(lib.yolo_conv_wgrad(dz.data_ptr(), dz_ld, 0, plan.view_ptr(xv), xv.ld, xv.off, dw.data_ptr(), B, xv.H, xv.W, cin,
-                                        cout, k, s, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), stream), "yolo_conv_wgrad")
+                                        cout, k, s, code, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), stream), "yolo_conv_wgrad")
             grads[id(cv.weight)] = dw
             done(cv.weight)
         # ---------------------------------------------------------------- dgrad into the input's gradient
         if xv.buf != prog.input.buf or want_input_grad:  # the image itself needs no gradient (train.py never asks)
             w = cv.weight.detach()
-            n_el = lib.yolo_packed_dgrad_elems(cout, cin, k)
+            flip = 1 if s == 1 else 0
             wp = plan.dgrad_w.get(i)
             if wp is None:
-                wp = plan.dgrad_w[i] = torch.empty(n_el, dtype=torch.float32, device=dev)
-            L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), wp.data_ptr(), cout, cin, k, 1 if s == 1 else 0, stream),
+                wp = plan.dgrad_w[i] = torch.empty(lib.yolo_packed_dgrad_bytes(cout, cin, k, flip, code), dtype=torch.uint8, device=dev)
+            L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), wp.data_ptr(), cout, cin, k, flip, code, stream),
                     "yolo_pack_weights_dgrad")
             optr, old, ooff, rptr, rld, roff = G.target(xv)
             if s == 1:
                 coutp = (cout + 31) // 32 * 32
                 src = TView(-1, coutp, Ho, Wo, dz_ld, 0)
-                d = _desc(B, src, coutp, cin, k, 1, old, ooff)
+                d = _desc(B, src, coutp, cin, k, 1, old, ooff, dtype=code)
                 if rptr:
                     d.r_ld, d.r_off = rld, roff
                     d.flags |= L.FLAG_RESIDUAL
@@ -302,7 +316,7 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
                         "dgrad (stride 1)")
             else:
                 L.check(lib.yolo_conv_dgrad_s2(dz.data_ptr(), dz_ld, 0, wp.data_ptr(), rptr, rld, roff, optr, old, ooff, B, Ho, Wo,
-                                               cin, cout, stream), "yolo_conv_dgrad_s2")
+                                               cin, cout, code, stream), "yolo_conv_dgrad_s2")
         # the gradient of this block's output is consumed: recycle its buffer (unless shared with a concat slice
         # whose other producer has not been processed yet)
         if yv is not None and op["out_mode"] != L.OUT_UPSAMPLE2X and not _shared_later(prog, i, yv.buf):
@@ -357,11 +371,14 @@ def forward_train(state, model, x):
     if Cc != model.in_channels or H != W or H % 32:
         raise ValueError(f"input must be (B,{model.in_channels},S,S) with S a multiple of 32, got {tuple(x.shape)}")
     with torch.cuda.device(x.device):
-        key = ("train", B, H, x.device.index)
+        dt = resolve_dtype(state.compute_dtype)           # autocast (train.py:53) selects the 16-bit kernels
+        key = ("train", B, H, x.device.index, dt)
         plan = state._plans.get(key)
         if plan is None:
             prog = build_network_program(model, B, H)
-            plan = state._plans[key] = TrainPlan(prog, x.device)
+            plan = state._plans[key] = TrainPlan(prog, x.device, dt)
+            if dt != "fp32" and not plan.stem:
+                raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
         plist = [p for p in model.parameters()]
         holder = (state, model, plan, plist)
         preds = YoloTrainFn.apply(x, holder, *plist)
@@ -379,8 +396,10 @@ def run_module_train(module, x):
     from .model import CNNBlock, ResidualBlock
     B, Cc, H, W = x.shape
     with torch.cuda.device(x.device):
+        dt = resolve_dtype(_module_state.compute_dtype)
         prog = Program(B)
-        cpad = (Cc + 3) // 4 * 4
+        al = 8 if dt != "fp32" else 4
+        cpad = (Cc + al - 1) // al * al
         cur = TView(prog.new_buf(H, W, cpad), Cc, H, W, cpad, 0)
         prog.input = cur
         if isinstance(module, CNNBlock):
@@ -389,7 +408,7 @@ def run_module_train(module, x):
             out = prog.emit_res(module, cur, nancheck=False)
         else:
             raise NotImplementedError("stand-alone training is provided for CNNBlock and ResidualBlock")
-        plan = TrainPlan(prog, x.device)
+        plan = TrainPlan(prog, x.device, dt)
         return _ModuleTrainFn.apply(x, (_module_state, module, plan, out), *list(module.parameters()))
 
 
@@ -403,7 +422,7 @@ class _ModuleTrainFn(torch.autograd.Function):
         lib = L.lib()
         y = torch.empty((plan.B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
         L.check(lib.yolo_nhwc_to_nchw(plan.ybuf[out.buf].data_ptr(), y.data_ptr(), plan.B, out.C, out.H, out.W, out.ld, out.off,
-                                      L.F32, L.current_stream()), "yolo_nhwc_to_nchw")
+                                      plan.code, L.current_stream()), "yolo_nhwc_to_nchw")
         ctx.holder = holder
         ctx.plist = list(module.parameters())
         ctx.xshape = tuple(x.shape)
@@ -419,13 +438,13 @@ class _ModuleTrainFn(torch.autograd.Function):
         need = {id(p): ctx.needs_input_grad[2 + j] for j, p in enumerate(ctx.plist)}
         # seed the gradient of the block output (NCHW -> NHWC) and make the input differentiable
         dyc = dy.float().contiguous()
-        g_out = torch.empty(plan.prog.buf_numel[out.buf], dtype=torch.float32, device=dev)
-        L.check(lib.yolo_nchw_to_nhwc(dyc.data_ptr(), g_out.data_ptr(), B, out.C, out.H, out.W, out.ld, L.F32, 0, stream), "seed")
+        g_out = torch.empty(plan.prog.buf_numel[out.buf], dtype=plan.tdtype, device=dev)
+        L.check(lib.yolo_nchw_to_nhwc(dyc.data_ptr(), g_out.data_ptr(), B, out.C, out.H, out.W, out.ld, plan.code, 0, stream), "seed")
         grads, gx = _backward(state, module, plan, [], need, seeds={out.buf: g_out}, want_input_grad=ctx.needs_input_grad[0])
         dx = None
         if gx is not None:
             Bc, Cc, H, W = ctx.xshape
             dx = torch.empty(ctx.xshape, dtype=torch.float32, device=dev)
             inp = plan.prog.input
-            L.check(lib.yolo_nhwc_to_nchw(gx.data_ptr(), dx.data_ptr(), Bc, Cc, H, W, inp.ld, 0, L.F32, stream), "dx")
+            L.check(lib.yolo_nhwc_to_nchw(gx.data_ptr(), dx.data_ptr(), Bc, Cc, H, W, inp.ld, 0, plan.code, stream), "dx")
         return (dx, None, *[grads.get(id(p)) if need[id(p)] else None for p in ctx.plist])
