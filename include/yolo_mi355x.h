@@ -154,6 +154,10 @@ int yolo_upsample2x_bwd(const void* dup, int d_ld, int d_off, void* dx, int x_ld
 size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride, int dtype);
 int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* dw_oihw, int n, int h,
                     int w, int cin, int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook for the gfx950 transposing LDS read (ds_read_b64_tr_b16) the 16-bit wgrad kernel is built on:
+ * in = [64][ld] 16-bit image; out[lane][8] = what lane receives as its 32x32x16 MFMA operand, i.e.
+ * in[8*(lane/32) + e][lane%32]. */
+int yolo_debug_tr_probe(const void* in, void* out, int ld, void* stream);
 /* Weights of the input-gradient convolution, from the fp32 OIHW master weights. flip = 1: stride-1 convs —
  * the result is a packed buffer for yolo_conv_fwd (same dtype) with (cin' = cout rounded up to 32,
  * cout' = cin, same ksize, stride 1): dx = conv(dz, W'). flip = 0: operand of yolo_conv_dgrad_s2 (always fp32). */

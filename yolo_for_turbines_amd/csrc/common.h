@@ -93,6 +93,12 @@ int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype
 int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s);
+// wgrad_h16.hip (bf16 / fp16 weight gradient, transposing LDS reads)
+bool wgrad_h16_eligible(int cin, int cout, int ks, int stride, int dz_ld, int dz_off, int x_ld, int x_off);
+size_t wgrad_h16_workspace(int n, int h, int w, int cin, int cout, int ks, int stride);
+int wgrad_h16_launch(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* partial, int n, int h, int w,
+                     int cin, int cout, int ks, int stride, int dtype, int* cout_pad, hipStream_t s);
+int tr_probe_launch(const void* in, void* out, int ld, hipStream_t s);
 // offset (elements) of the fragment-order copy inside a packed weight buffer
 inline size_t v0_packed_elems(int cout, int cin, int ks) { return (size_t)coutpad_of(cout) * kpad_of(cin, ks); }
 

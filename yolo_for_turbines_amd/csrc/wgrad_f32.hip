@@ -198,7 +198,19 @@ size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ks
     if (dtype != YOLO_F32 && dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     const WgradPlan q = plan_wgrad(n, h, w, cin, cout, ksize, stride);
-    return (size_t)q.nslices * q.cout_pad * q.kp * sizeof(float);
+    size_t need = (size_t)q.nslices * q.cout_pad * q.kp * sizeof(float);
+    if (dtype != YOLO_F32 && cin >= 32 && !(cin & 7)) {
+        const size_t nh = wgrad_h16_workspace(n, h, w, cin, cout, ksize, stride);
+        if (nh > need) need = nh;
+    }
+    return need;
+}
+
+/* probe of the gfx950 transposing LDS read used by the 16-bit wgrad kernel (tests only):
+ * in: [64][ld] 16-bit image, out: [64 lanes][8] what each lane receives for the 32x32x16 operand */
+int yolo_debug_tr_probe(const void* in, void* out, int ld, void* stream) {
+    if (!in || !out || ld < 32 || ld > 128 || (ld & 3)) return fail(YOLO_ERR_ARG, "tr_probe: bad arguments");
+    return tr_probe_launch(in, out, ld, (hipStream_t)stream);
 }
 
 /* dz: NHWC gradient of the raw conv output (n, ho, wo, cout) with channel stride dz_ld (>= cout rounded
@@ -212,6 +224,18 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
     const int cp = cin_pad_of(cin);
     if ((dz_ld & 3) || (dz_off & 3) || (x_ld & 3) || (x_off & 3) || x_ld < cp || dz_ld < ((cout + 3) & ~3))
         return fail(YOLO_ERR_ARG, "wgrad: ld/off must be multiples of 4 and cover the padded channels");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)cout * cin * ksize * ksize;
+    const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype != YOLO_F32 && wgrad_h16_eligible(cin, cout, ksize, stride, dz_ld, dz_off, x_ld, x_off)) {
+        int cout_pad = 0;
+        const int ns = wgrad_h16_launch(dz, dz_ld, dz_off, x, x_ld, x_off, (float*)workspace, n, h, w, cin, cout, ksize, stride, dtype,
+                                        &cout_pad, s);
+        if (ns < 0) return ns;
+        hipLaunchKernelGGL(wgrad_reduce, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw_oihw, ns, cout, cin, cp,
+                           ksize * ksize, cout_pad, total);
+        return check_launch("wgrad_reduce");
+    }
     const WgradPlan q = plan_wgrad(n, h, w, cin, cout, ksize, stride);
     WgradArgs a;
     a.dz = dz; a.x = x; a.partial = (float*)workspace;
@@ -223,7 +247,6 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
     a.dz_ld = dz_ld; a.dz_off = dz_off; a.x_ld = x_ld; a.x_off = x_off;
     a.Kp = q.kp; a.total_steps = q.total_steps; a.steps_per_slice = q.steps_per_slice;
     a.tiles_n = q.tiles_n; a.tiles_per_tap = q.tiles_per_tap; a.cout_pad = q.cout_pad;
-    hipStream_t s = (hipStream_t)stream;
     dim3 grid(q.tiles_m * q.tiles_n, q.nslices), block(256);
     YOLO_DISPATCH_DTYPE(dtype, "wgrad",
         if (q.smallc) {
@@ -235,8 +258,6 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
         else hipLaunchKernelGGL((wgrad_f32_kernel<T, 64, 64, false>), grid, block, 0, s, a));
     int rc = check_launch("wgrad_f32");
     if (rc) return rc;
-    const long long total = (long long)cout * cin * ksize * ksize;
-    const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw_oihw, q.nslices, cout, cin, cp,
                        ksize * ksize, q.cout_pad, total);
     return check_launch("wgrad_reduce");
