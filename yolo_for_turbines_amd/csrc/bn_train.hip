@@ -41,76 +41,99 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     return 1.f;
 }
 
-// Thread layout shared by the reductions: C4 = C/4 vector channels; thread t owns vector channel
-// t % VC (VC = min(C4, 256)) and pixel lane t / VC; a block covers every channel of its pixel range.
+// VN consecutive per-channel parameters (fp32) as 16-byte loads
+template <int VN>
+__device__ __forceinline__ void ldp(const float* __restrict__ p, float (&v)[VN]) {
+#pragma unroll
+    for (int k = 0; k < VN / 4; ++k) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p + 4 * k);
+        v[4 * k] = r[0]; v[4 * k + 1] = r[1]; v[4 * k + 2] = r[2]; v[4 * k + 3] = r[3];
+    }
+}
+
+// Thread layout shared by the reductions: every thread moves 16-byte vectors (VN = 4 fp32 or 8 halfs);
+// CV = C/VN vector channels; thread t owns vector channel t % VC (VC = min(CV, 256)) and pixel lane
+// t / VC; a block covers every channel of its pixel range.
 struct RedGeom { int vc, lanes, passes; };
-__device__ __forceinline__ RedGeom red_geom(int c4) {
+__device__ __forceinline__ RedGeom red_geom(int cv) {
     RedGeom g;
-    g.vc = c4 < 256 ? c4 : 256;
+    g.vc = cv < 256 ? cv : 256;
     g.lanes = 256 / g.vc;
-    g.passes = (c4 + g.vc - 1) / g.vc;
+    g.passes = (cv + g.vc - 1) / g.vc;
     return g;
+}
+
+// fixed-order reduction over the pixel lanes of a block through LDS, one channel component at a time
+template <int VN>
+__device__ __forceinline__ void block_reduce_store(double (&s)[VN], double (&q)[VN], const RedGeom& g, int t, int v, int lane,
+                                                   bool own, double* __restrict__ dst /* partial + (blk*c + vch*VN)*2 */) {
+    __shared__ double red[256][2];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+        __syncthreads();
+        red[t][0] = s[e];
+        red[t][1] = q[e];
+        __syncthreads();
+        if (lane == 0 && own) {
+            double a = 0, b = 0;
+            for (int l = 0; l < g.lanes; ++l) { a += red[l * g.vc + v][0]; b += red[l * g.vc + v][1]; }
+            dst[e * 2] = a;
+            dst[e * 2 + 1] = b;
+        }
+    }
 }
 
 // partial[blk][c][2] (double): sum z, sum z^2 over the block's pixel range
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S* __restrict__ z, int m, int c, int ld, int off,
                                                         int pix_per_block, double* __restrict__ partial) {
-    __shared__ double red[256][2];
-    const int c4 = c >> 2;
-    const RedGeom g = red_geom(c4);
+    constexpr int VN = Vec16<T>::VN;
+    const int cv = c / VN;
+    const RedGeom g = red_geom(cv);
     const int t = threadIdx.x;
     const int v = t % g.vc, lane = t / g.vc;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = p0 + pix_per_block < m ? p0 + pix_per_block : m;
     for (int pass = 0; pass < g.passes; ++pass) {
         const int vch = pass * g.vc + v;
-        double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-        if (vch < c4 && lane < g.lanes) {
-            float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+        double s[VN], q[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { s[e] = 0; q[e] = 0; }
+        const bool own = vch < cv && lane < g.lanes;
+        if (own) {
+            float fs[VN], fq[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { fs[e] = 0.f; fq[e] = 0.f; }
             int run = 0;
-            const typename Elt<T>::S* zp = z + off + vch * 4;
+            const typename Elt<T>::S* zp = z + off + vch * VN;
             int p = p0 + lane;
             // 4 independent 16-byte loads in flight per thread (one-at-a-time left the kernel at ~45 % of
             // the achievable HBM rate: latency-bound, not bandwidth-bound)
             for (; p + 3 * g.lanes < p1; p += 4 * g.lanes) {
-                f32x4 x[4];
+                float x[4][VN];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = Elt<T>::ld4(zp + (size_t)(p + u * g.lanes) * ld);
+                for (int u = 0; u < 4; ++u) Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * ld, x[u]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { fs[e] += x[u][e]; fq[e] += x[u][e] * x[u][e]; }
+                    for (int e = 0; e < VN; ++e) { fs[e] += x[u][e]; fq[e] += x[u][e] * x[u][e]; }
                 run += 4;
                 if (run >= 64) {                         // flush short fp32 runs into fp64
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                    for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
                     run = 0;
                 }
             }
             for (; p < p1; p += g.lanes) {
-                const f32x4 x = Elt<T>::ld4(zp + (size_t)p * ld);
+                float x[VN];
+                Vec16<T>::ld(zp + (size_t)p * ld, x);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fs[e] += x[e]; fq[e] += x[e] * x[e]; }
+                for (int e = 0; e < VN; ++e) { fs[e] += x[e]; fq[e] += x[e] * x[e]; }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
+            for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
         }
-        // reduce over pixel lanes (fixed order) through LDS, one channel component at a time
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __syncthreads();
-            red[t][0] = s[e];
-            red[t][1] = q[e];
-            __syncthreads();
-            if (lane == 0 && vch < c4) {
-                double a = 0, b = 0;
-                for (int l = 0; l < g.lanes; ++l) { a += red[l * g.vc + v][0]; b += red[l * g.vc + v][1]; }
-                double* dst = partial + ((size_t)blockIdx.x * c + vch * 4 + e) * 2;
-                dst[0] = a;
-                dst[1] = b;
-            }
-        }
+        block_reduce_store<VN>(s, q, g, t, v, lane, vch < cv, partial + ((size_t)blockIdx.x * c + vch * VN) * 2);
     }
 }
 
@@ -164,7 +187,8 @@ __global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, 
     }
 }
 
-// y = act(z*scale + shift) [+ residual], float4 per thread, same output modes as the conv epilogue
+// y = act((z - mean)*scale + shift) [+ residual], one 16-byte vector per thread and iteration, same output
+// modes as the conv epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                          const float* __restrict__ mean,
@@ -172,22 +196,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
                                                          const typename Elt<T>::S* __restrict__ res, int r_ld, int r_off,
                                                          typename Elt<T>::S* __restrict__ y, int y_ld, int y_off, long long m, int c,
                                                          int Ho, int Wo, int act, int out_mode, int* nan_flag) {
-    const int c4 = c >> 2;
-    const long long total = m * c4;
+    constexpr int VN = Vec16<T>::VN;
+    const int cv = c / VN;
+    const long long total = m * cv;
     bool bad = false;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / c4;
-        const int ch = (int)(i - p * c4) * 4;
-        const f32x4 x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + ch);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
-        f32x4 mu = {0.f, 0.f, 0.f, 0.f};
-        if (mean) mu = *reinterpret_cast<const f32x4*>(mean + ch);
-        f32x4 v;
+        const long long p = i / cv;
+        const int ch = (int)(i - p * cv) * VN;
+        float x[VN], v[VN], mu[VN], sc[VN], sh[VN];
+        Vec16<T>::ld(z + (size_t)p * z_ld + z_off + ch, x);
+        ldp<VN>(scale + ch, sc);
+        ldp<VN>(shift + ch, sh);
+        if (mean) ldp<VN>(mean + ch, mu);
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fwd((x[e] - mu[e]) * sc[e] + sh[e], act);
-        if (res) v += Elt<T>::ld4(res + (size_t)p * r_ld + r_off + ch);
-        bad |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
+            for (int e = 0; e < VN; ++e) mu[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = act_fwd((x[e] - mu[e]) * sc[e] + sh[e], act);
+        if (res) {
+            float r[VN];
+            Vec16<T>::ld(res + (size_t)p * r_ld + r_off + ch, r);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) bad |= (v[e] != v[e]);
         if (out_mode == YOLO_OUT_UPSAMPLE2X) {
             const long long hw = (long long)Ho * Wo;
             const long long img = p / hw;
@@ -195,93 +229,92 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
             const int ho = rem / Wo, wo = rem - ho * Wo;
             const int W2 = 2 * Wo;
             typename Elt<T>::S* d = y + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * y_ld + y_off + ch;
-            Elt<T>::st4(d, v);
-            Elt<T>::st4(d + y_ld, v);
-            Elt<T>::st4(d + (size_t)W2 * y_ld, v);
-            Elt<T>::st4(d + (size_t)(W2 + 1) * y_ld, v);
+            Vec16<T>::st(d, v);
+            Vec16<T>::st(d + y_ld, v);
+            Vec16<T>::st(d + (size_t)W2 * y_ld, v);
+            Vec16<T>::st(d + (size_t)(W2 + 1) * y_ld, v);
         } else {
-            Elt<T>::st4(y + (size_t)p * y_ld + y_off + ch, v);
+            Vec16<T>::st(y + (size_t)p * y_ld + y_off + ch, v);
         }
     }
     if (bad && nan_flag) atomicOr(nan_flag, 2);
 }
 
-// partial[blk][c][2]: sum du, sum du*zhat.  gamma == nullptr: bare conv (du = dy, only sum du is used)
+// partial[blk][c][2]: sum du, sum du*zhat.  mean == nullptr: bare conv (du = dy, only sum du is used)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
                                                       const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       int m, int c, int act, int pix_per_block, double* __restrict__ partial) {
-    __shared__ double red[256][2];
-    const int c4 = c >> 2;
-    const RedGeom g = red_geom(c4);
+    constexpr int VN = Vec16<T>::VN;
+    const int cv = c / VN;
+    const RedGeom g = red_geom(cv);
     const int t = threadIdx.x;
     const int v = t % g.vc, lane = t / g.vc;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = p0 + pix_per_block < m ? p0 + pix_per_block : m;
     for (int pass = 0; pass < g.passes; ++pass) {
         const int vch = pass * g.vc + v;
-        double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-        if (vch < c4 && lane < g.lanes) {
-            f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-            if (mean) {
-                mu = *reinterpret_cast<const f32x4*>(mean + vch * 4);
-                is = *reinterpret_cast<const f32x4*>(invstd + vch * 4);
-                sc = *reinterpret_cast<const f32x4*>(scale + vch * 4);
-                sh = *reinterpret_cast<const f32x4*>(shift + vch * 4);
-            }
-            float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
-            int run = 0;
-            auto accum = [&](const f32x4& d, const f32x4& x) {
+        double s[VN], q[VN];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VN; ++e) { s[e] = 0; q[e] = 0; }
+        if (vch < cv && lane < g.lanes) {
+            float mu[VN], is[VN], sc[VN], sh[VN], fs[VN], fq[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { mu[e] = 0.f; is[e] = 1.f; sc[e] = 1.f; sh[e] = 0.f; fs[e] = 0.f; fq[e] = 0.f; }
+            if (mean) {
+                ldp<VN>(mean + vch * VN, mu);
+                ldp<VN>(invstd + vch * VN, is);
+                ldp<VN>(scale + vch * VN, sc);
+                ldp<VN>(shift + vch * VN, sh);
+            }
+            int run = 0;
+            auto accum = [&](const float (&d)[VN], const float (&x)[VN]) {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
                     const float du = mean ? d[e] * act_grad((x[e] - mu[e]) * sc[e] + sh[e], act) : d[e];
                     fs[e] += du;
                     fq[e] += du * ((x[e] - mu[e]) * is[e]);
                 }
             };
+            const typename Elt<T>::S* dp = dy + dy_off + vch * VN;
+            const typename Elt<T>::S* zp = z + z_off + vch * VN;
             int p = p0 + lane;
             for (; p + g.lanes < p1; p += 2 * g.lanes) {          // 4 loads in flight (2 pixels x {dy, z})
-                const f32x4 d0 = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + vch * 4);
-                const f32x4 d1 = Elt<T>::ld4(dy + (size_t)(p + g.lanes) * dy_ld + dy_off + vch * 4);
-                f32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+                float d0[VN], d1[VN], x0[VN], x1[VN];
+                Vec16<T>::ld(dp + (size_t)p * dy_ld, d0);
+                Vec16<T>::ld(dp + (size_t)(p + g.lanes) * dy_ld, d1);
                 if (mean) {
-                    x0 = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + vch * 4);
-                    x1 = Elt<T>::ld4(z + (size_t)(p + g.lanes) * z_ld + z_off + vch * 4);
+                    Vec16<T>::ld(zp + (size_t)p * z_ld, x0);
+                    Vec16<T>::ld(zp + (size_t)(p + g.lanes) * z_ld, x1);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
                 }
                 accum(d0, x0);
                 accum(d1, x1);
                 run += 2;
                 if (run >= 64) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                    for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
                     run = 0;
                 }
             }
             for (; p < p1; p += g.lanes) {
-                const f32x4 d = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + vch * 4);
-                f32x4 x = {0, 0, 0, 0};
-                if (mean) x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + vch * 4);
+                float d[VN], x[VN];
+                Vec16<T>::ld(dp + (size_t)p * dy_ld, d);
+                if (mean) Vec16<T>::ld(zp + (size_t)p * z_ld, x);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) x[e] = 0.f;
+                }
                 accum(d, x);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
+            for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __syncthreads();
-            red[t][0] = s[e];
-            red[t][1] = q[e];
-            __syncthreads();
-            if (lane == 0 && vch < c4) {
-                double a = 0, b = 0;
-                for (int l = 0; l < g.lanes; ++l) { a += red[l * g.vc + v][0]; b += red[l * g.vc + v][1]; }
-                double* dst = partial + ((size_t)blockIdx.x * c + vch * 4 + e) * 2;
-                dst[0] = a;
-                dst[1] = b;
-            }
-        }
+        block_reduce_store<VN>(s, q, g, t, v, lane, vch < cv, partial + ((size_t)blockIdx.x * c + vch * VN) * 2);
     }
 }
 
@@ -296,9 +329,9 @@ __global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, in
     dbeta[ch] = (float)s;
     if (!gamma) return;
     dgamma[ch] = (float)q;
-    coef[ch * 3 + 0] = gamma[ch] * invstd[ch];          // k0
-    coef[ch * 3 + 1] = (float)(s / m);                  // mean(du)
-    coef[ch * 3 + 2] = (float)(q / m);                  // mean(du * zhat)
+    coef[ch] = gamma[ch] * invstd[ch];                  // k0          (planar [3][c]: vector loads in the apply pass)
+    coef[c + ch] = (float)(s / m);                      // mean(du)
+    coef[2 * c + ch] = (float)(q / m);                  // mean(du * zhat)
 }
 
 template <typename T>
@@ -308,25 +341,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ coef, typename Elt<T>::S* __restrict__ dz, int dz_ld,
                                                     int dz_off, long long m, int c, int act) {
-    const int c4 = c >> 2;
-    const long long total = m * c4;
+    constexpr int VN = Vec16<T>::VN;
+    const int cv = c / VN;
+    const long long total = m * cv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / c4;
-        const int ch = (int)(i - p * c4) * 4;
-        const f32x4 d = Elt<T>::ld4(dy + (size_t)p * dy_ld + dy_off + ch);
-        const f32x4 x = Elt<T>::ld4(z + (size_t)p * z_ld + z_off + ch);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + ch);
-        f32x4 o;
+        const long long p = i / cv;
+        const int ch = (int)(i - p * cv) * VN;
+        float d[VN], x[VN], o[VN], mu[VN], is[VN], sc[VN], sh[VN], k0[VN], k1[VN], k2[VN];
+        Vec16<T>::ld(dy + (size_t)p * dy_ld + dy_off + ch, d);
+        Vec16<T>::ld(z + (size_t)p * z_ld + z_off + ch, x);
+        ldp<VN>(mean + ch, mu);
+        ldp<VN>(invstd + ch, is);
+        ldp<VN>(scale + ch, sc);
+        ldp<VN>(shift + ch, sh);
+        ldp<VN>(coef + ch, k0);
+        ldp<VN>(coef + c + ch, k1);
+        ldp<VN>(coef + 2 * c + ch, k2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VN; ++e) {
             const float xc = x[e] - mu[e];
             const float du = d[e] * act_grad(xc * sc[e] + sh[e], act);
-            o[e] = coef[(ch + e) * 3] * (du - coef[(ch + e) * 3 + 1] - xc * is[e] * coef[(ch + e) * 3 + 2]);
+            o[e] = k0[e] * (du - k1[e] - xc * is[e] * k2[e]);
         }
-        Elt<T>::st4(dz + (size_t)p * dz_ld + dz_off + ch, o);
+        Vec16<T>::st(dz + (size_t)p * dz_ld + dz_off + ch, o);
     }
 }
 
@@ -335,22 +372,26 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const typename Elt<T>::S* __restrict__ dup, int d_ld, int d_off,
                                                              typename Elt<T>::S* __restrict__ dx, int x_ld, int x_off, long long m,
                                                              int c, int Ho, int Wo) {
-    const int c4 = c >> 2;
-    const long long total = m * c4;
+    constexpr int VN = Vec16<T>::VN;
+    const int cv = c / VN;
+    const long long total = m * cv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / c4;
-        const int ch = (int)(i - p * c4) * 4;
+        const long long p = i / cv;
+        const int ch = (int)(i - p * cv) * VN;
         const long long hw = (long long)Ho * Wo;
         const long long img = p / hw;
         const int rem = (int)(p - img * hw);
         const int ho = rem / Wo, wo = rem - ho * Wo;
         const int W2 = 2 * Wo;
         const typename Elt<T>::S* s = dup + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * d_ld + d_off + ch;
-        f32x4 v = Elt<T>::ld4(s);
-        v += Elt<T>::ld4(s + d_ld);
-        v += Elt<T>::ld4(s + (size_t)W2 * d_ld);
-        v += Elt<T>::ld4(s + (size_t)(W2 + 1) * d_ld);
-        Elt<T>::st4(dx + (size_t)p * x_ld + x_off + ch, v);
+        float a[VN], b[VN], cc[VN], d[VN];
+        Vec16<T>::ld(s, a);
+        Vec16<T>::ld(s + d_ld, b);
+        Vec16<T>::ld(s + (size_t)W2 * d_ld, cc);
+        Vec16<T>::ld(s + (size_t)(W2 + 1) * d_ld, d);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) a[e] = (a[e] + b[e]) + (cc[e] + d[e]);
+        Vec16<T>::st(dx + (size_t)p * x_ld + x_off + ch, a);
     }
 }
 
@@ -384,7 +425,8 @@ int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gam
                   float eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                   float* shift, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!z || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace) return fail(YOLO_ERR_ARG, "bn_stats: null pointer");
-    if (m <= 0 || c <= 0 || (c & 3) || (ld & 3) || (off & 3) || ld < c) return fail(YOLO_ERR_ARG, "bn_stats: c/ld/off must be multiples of 4");
+    const int vn = dtype == YOLO_F32 ? 4 : 8;
+    if (m <= 0 || c <= 0 || (c % vn) || (ld % vn) || (off % vn) || ld < c) return fail(YOLO_ERR_ARG, "bn_stats: c/ld/off must be multiples of %d", vn);
     if (workspace_bytes < yolo_bn_workspace_bytes(m, c)) return fail(YOLO_ERR_WORKSPACE, "bn_stats: workspace too small");
     int ppb;
     const int nblk = red_blocks(m, &ppb);
@@ -402,12 +444,13 @@ int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const
                     int r_ld, int r_off, void* y, int y_ld, int y_off, int n, int h, int w, int c, int act, int out_mode,
                     int dtype, int32_t* nan_flag, void* stream) {
     if (!z || !scale || !shift || !y) return fail(YOLO_ERR_ARG, "bn_act_fwd: null pointer");
-    if ((c & 3) || (z_ld & 3) || (z_off & 3) || (y_ld & 3) || (y_off & 3) || (residual && ((r_ld & 3) || (r_off & 3))))
-        return fail(YOLO_ERR_ARG, "bn_act_fwd: channel counts / strides must be multiples of 4");
+    const int vn = dtype == YOLO_F32 ? 4 : 8;
+    if ((c % vn) || (z_ld % vn) || (z_off % vn) || (y_ld % vn) || (y_off % vn) || (residual && ((r_ld % vn) || (r_off % vn))))
+        return fail(YOLO_ERR_ARG, "bn_act_fwd: channel counts / strides must be multiples of %d", vn);
     if (out_mode != YOLO_OUT_NHWC && out_mode != YOLO_OUT_UPSAMPLE2X) return fail(YOLO_ERR_ARG, "bn_act_fwd: out_mode");
     const long long m = (long long)n * h * w;
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_fwd",
-        hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z, z_ld,
+        hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(m * (c / vn))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z, z_ld,
                            z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, m, c, h, w, act,
                            out_mode, nan_flag));
     return check_launch("bn_act_fwd");
@@ -419,7 +462,9 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
                     void* stream) {
     if (!dy || !dbeta || !workspace) return fail(YOLO_ERR_ARG, "bn_act_bwd: null pointer");
     if (gamma && (!z || !mean || !invstd || !scale || !shift || !dgamma || !dz)) return fail(YOLO_ERR_ARG, "bn_act_bwd: null pointer");
-    if (m <= 0 || c <= 0 || (c & 3) || (dy_ld & 3) || (dy_off & 3)) return fail(YOLO_ERR_ARG, "bn_act_bwd: c/ld/off must be multiples of 4");
+    const int vn = dtype == YOLO_F32 ? 4 : 8;
+    if (m <= 0 || c <= 0 || (c % vn) || (dy_ld % vn) || (dy_off % vn) || (gamma && ((z_ld % vn) || (z_off % vn) || (dz_ld % vn) || (dz_off % vn))))
+        return fail(YOLO_ERR_ARG, "bn_act_bwd: c/ld/off must be multiples of %d", vn);
     if (workspace_bytes < yolo_bn_workspace_bytes(m, c)) return fail(YOLO_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
     int ppb;
     const int nblk = red_blocks(m, &ppb);
@@ -435,17 +480,18 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
     rc = check_launch("bn_bwd_finalize");
     if (rc || !gamma) return rc;
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
-        hipLaunchKernelGGL(bn_bwd_apply<T>, dim3(ew_grid((long long)m * (c / 4))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+        hipLaunchKernelGGL(bn_bwd_apply<T>, dim3(ew_grid((long long)m * (c / vn))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
                            (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, (long long)m, c, act));
     return check_launch("bn_bwd_apply");
 }
 
 int yolo_upsample2x_bwd(const void* dup, int d_ld, int d_off, void* dx, int x_ld, int x_off, int n, int h, int w, int c,
                         int dtype, void* stream) {
-    if (!dup || !dx || (c & 3) || (d_ld & 3) || (d_off & 3) || (x_ld & 3) || (x_off & 3)) return fail(YOLO_ERR_ARG, "upsample2x_bwd: bad arguments");
+    const int vn = dtype == YOLO_F32 ? 4 : 8;
+    if (!dup || !dx || (c % vn) || (d_ld % vn) || (d_off % vn) || (x_ld % vn) || (x_off % vn)) return fail(YOLO_ERR_ARG, "upsample2x_bwd: bad arguments");
     const long long m = (long long)n * h * w;
     YOLO_DISPATCH_DTYPE(dtype, "upsample2x_bwd",
-        hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_grid(m * (c / 4))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)dup, d_ld,
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_grid(m * (c / vn))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)dup, d_ld,
                            d_off, (Elt<T>::S*)dx, x_ld, x_off, m, c, h, w));
     return check_launch("upsample2x_bwd");
 }

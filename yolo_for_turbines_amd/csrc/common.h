@@ -71,6 +71,50 @@ template <> struct Elt<_Float16> {
     static __device__ __forceinline__ void st(S* p, float v) { *reinterpret_cast<_Float16*>(p) = (_Float16)v; }
 };
 
+// 16-byte vectors for the HBM-bound passes: VN elements (4 fp32 / 8 halfs) per load
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int VN = 4;
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+        v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+        const f32x4 r = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = r;
+    }
+};
+template <> struct Vec16<__bf16> {
+    static constexpr int VN = 8;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(const unsigned short* p, float (&v)[8]) {
+        const u4 r = *reinterpret_cast<const u4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void st(unsigned short* p, const float (&v)[8]) {
+        u4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (unsigned)Elt<__bf16>::cvt(v[2 * e]) | ((unsigned)Elt<__bf16>::cvt(v[2 * e + 1]) << 16);
+        *reinterpret_cast<u4*>(p) = r;
+    }
+};
+template <> struct Vec16<_Float16> {
+    static constexpr int VN = 8;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void ld(const unsigned short* p, float (&v)[8]) {
+        const h8 r = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)r[e];
+    }
+    static __device__ __forceinline__ void st(unsigned short* p, const float (&v)[8]) {
+        h8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (_Float16)v[e];
+        *reinterpret_cast<h8*>(p) = r;
+    }
+};
+
 // run `body` with T bound to the element type of `dtype` (host side)
 #define YOLO_DISPATCH_DTYPE(dtype, what, ...)                                             \
     switch (dtype) {                                                                      \

@@ -264,7 +264,7 @@ static WgradHPlan plan_wgrad_h(int n, int h, int w, int cin, int cout, int ks, i
         q.total_tiles = (int)(((long long)n * ho * wo + q.th * 16 - 1) / (q.th * 16));
     }
     const int ntile = q.tiles_m * q.tiles_n;
-    int want = ceil_div(1024, ntile);
+    int want = ceil_div(512, ntile);                       // one resident wave of blocks: partial traffic = blocks x tile
     int maxs = ceil_div(q.total_tiles, 8);                  // at least 8 K tiles per slice
     if (maxs < 1) maxs = 1;
     int ns = want < 1 ? 1 : (want > maxs ? maxs : want);

@@ -199,6 +199,7 @@ class PackedBlock:
         if stem_ok:
             self.stem_w = torch.empty(27 * cv.out_channels, dtype=torch.float32, device=device)   # [27][cout]
         self.stamp = None
+        self.folded = False
 
     @staticmethod
     def stamp_of(block):
@@ -210,7 +211,8 @@ class PackedBlock:
             ts.append(block.conv.bias)
         return tuple((t.data_ptr(), t._version) for t in ts)
 
-    def refresh(self, block, stream):
+    def refresh(self, block, stream, fold_bn=True):
+        """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold."""
         lib = L.lib()
         cv = block.conv
         w = cv.weight.detach()
@@ -221,7 +223,10 @@ class PackedBlock:
                                           cv.kernel_size[0], self.code, stream), "yolo_pack_weights")
         if self.stem_w is not None:
             L.check(lib.yolo_stem_pack(w.data_ptr(), self.stem_w.data_ptr(), cv.out_channels, stream), "yolo_stem_pack")
-        if block.batch_norm_act:
+        self.folded = True
+        if block.batch_norm_act and not fold_bn:
+            self.folded = False
+        elif block.batch_norm_act:
             bn = block.batch_norm
             g, b, m, v = (t.detach().float().contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
             L.check(lib.yolo_bn_fold(g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), float(bn.eps),
@@ -382,11 +387,11 @@ class ModelState:
             pk = per_dev[(device.index, dtype)] = PackedBlock(block, device, dtype)
         return pk
 
-    def refresh_weights(self, blocks, device, stream, dtype="fp32"):
+    def refresh_weights(self, blocks, device, stream, dtype="fp32", fold_bn=True):
         for blk in blocks:
             pk = self.packed(blk, device, dtype)
-            if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk):
-                pk.refresh(blk, stream)
+            if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk) or (fold_bn and not pk.folded):
+                pk.refresh(blk, stream, fold_bn)
 
     # ------------------------------------------------------------------ inference forward
     def forward(self, model, x):

@@ -91,7 +91,7 @@ def _forward(state, model, plan: TrainPlan, x):
     ones, zeros = _consts(dev)
     blocks = [op["block"] for op in prog.ops]
     code = plan.code
-    state.refresh_weights(blocks, dev, stream, plan.dtype)
+    state.refresh_weights(blocks, dev, stream, plan.dtype, fold_bn=False)
     plan.nan_flag.zero_()
     xin = x.detach()
     if xin.dtype != torch.float32 or not xin.is_contiguous():
