@@ -84,7 +84,7 @@ __device__ __forceinline__ void block_reduce_store(double (&s)[VN], double (&q)[
 }
 
 // partial[blk][c][2] (double): sum z, sum z^2 over the block's pixel range
-template <typename T>
+template <typename T, bool LONG>
 __global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S* __restrict__ z, int m, int c, int ld, int off,
                                                         int pix_per_block, double* __restrict__ partial) {
     constexpr int VN = Vec16<T>::VN;
@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int e = 0; e < VN; ++e) { fs[e] += x[u][e]; fq[e] += x[u][e] * x[u][e]; }
-                run += 4;
-                if (run >= 64) {                         // flush short fp32 runs into fp64
+                if constexpr (LONG) {                    // only huge inputs: flush fp32 runs into fp64 (costs 4*VN VGPRs)
+                    run += 4;
+                    if (run >= 64) {
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
-                    run = 0;
+                        for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                        run = 0;
+                    }
                 }
             }
             for (; p < p1; p += g.lanes) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
 }
 
 // partial[blk][c][2]: sum du, sum du*zhat.  mean == nullptr: bare conv (du = dy, only sum du is used)
-template <typename T>
+template <typename T, bool LONG>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
                                                       const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -294,11 +296,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* 
                 }
                 accum(d0, x0);
                 accum(d1, x1);
-                run += 2;
-                if (run >= 64) {
+                if constexpr (LONG) {
+                    run += 2;
+                    if (run >= 64) {
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
-                    run = 0;
+                        for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                        run = 0;
+                    }
                 }
             }
             for (; p < p1; p += g.lanes) {
@@ -395,12 +399,20 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const typename Elt<
     }
 }
 
-static int red_blocks(int m, int* pix_per_block) {
-    int nblk = (m + 255) / 256;
-    if (nblk > 2048) nblk = 2048;
+// Blocks of the reductions: each thread accumulates a short fp32 run (~32 pixels) before the fp64 tree, so the
+// kernels need no per-thread fp64 state (that cost 3 of 8 waves/SIMD); `*long_run` selects the variant with
+// in-loop fp64 flushes for inputs so large that the block cap makes the runs long.
+static int red_blocks(int m, int c, int vn, int* pix_per_block, bool* long_run) {
+    const int cv = c / vn;
+    const int lanes = 256 / (cv < 256 ? cv : 256);
+    int ppb = 32 * lanes;
+    int nblk = (m + ppb - 1) / ppb;
+    if (nblk > 4096) nblk = 4096;
     if (nblk < 1) nblk = 1;
-    *pix_per_block = (m + nblk - 1) / nblk;
-    return (m + *pix_per_block - 1) / *pix_per_block;
+    ppb = (m + nblk - 1) / nblk;
+    *pix_per_block = ppb;
+    if (long_run) *long_run = ppb / lanes > 256;
+    return (m + ppb - 1) / ppb;
 }
 
 static int ew_grid(long long total) {
@@ -417,7 +429,8 @@ extern "C" {
 size_t yolo_bn_workspace_bytes(int m, int c) {
     if (m <= 0 || c <= 0) return 0;
     int ppb;
-    const int nblk = red_blocks(m, &ppb);
+    const int c4 = (c + 3) & ~3;
+    const int nblk = red_blocks(m, c4, 4, &ppb, nullptr);      // fp32 vectors give the most blocks: upper bound for every dtype
     return (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 3 * sizeof(float);
 }
 
@@ -429,10 +442,12 @@ int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gam
     if (m <= 0 || c <= 0 || (c % vn) || (ld % vn) || (off % vn) || ld < c) return fail(YOLO_ERR_ARG, "bn_stats: c/ld/off must be multiples of %d", vn);
     if (workspace_bytes < yolo_bn_workspace_bytes(m, c)) return fail(YOLO_ERR_WORKSPACE, "bn_stats: workspace too small");
     int ppb;
-    const int nblk = red_blocks(m, &ppb);
+    bool lr;
+    const int nblk = red_blocks(m, c, vn, &ppb, &lr);
     hipStream_t s = (hipStream_t)stream;
     YOLO_DISPATCH_DTYPE(dtype, "bn_stats",
-        hipLaunchKernelGGL(bn_stats_partial<T>, dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)z, m, c, ld, off, ppb, (double*)workspace));
+        if (lr) hipLaunchKernelGGL((bn_stats_partial<T, true>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)z, m, c, ld, off, ppb, (double*)workspace);
+        else hipLaunchKernelGGL((bn_stats_partial<T, false>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)z, m, c, ld, off, ppb, (double*)workspace));
     int rc = check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, (const double*)workspace, nblk, m, c, momentum,
@@ -467,13 +482,16 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
         return fail(YOLO_ERR_ARG, "bn_act_bwd: c/ld/off must be multiples of %d", vn);
     if (workspace_bytes < yolo_bn_workspace_bytes(m, c)) return fail(YOLO_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
     int ppb;
-    const int nblk = red_blocks(m, &ppb);
+    bool lr;
+    const int nblk = red_blocks(m, c, vn, &ppb, &lr);
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)nblk * c * 2 * sizeof(double));
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
-        hipLaunchKernelGGL(bn_bwd_partial<T>, dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld, z_off,
-                           gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part));
+        if (lr) hipLaunchKernelGGL((bn_bwd_partial<T, true>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld,
+                                   z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part);
+        else hipLaunchKernelGGL((bn_bwd_partial<T, false>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld,
+                                z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part));
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
