@@ -160,7 +160,8 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
 int yolo_debug_tr_probe(const void* in, void* out, int ld, void* stream);
 /* Weights of the input-gradient convolution, from the fp32 OIHW master weights. flip = 1: stride-1 convs —
  * the result is a packed buffer for yolo_conv_fwd (same dtype) with (cin' = cout rounded up to 32,
- * cout' = cin, same ksize, stride 1): dx = conv(dz, W'). flip = 0: operand of yolo_conv_dgrad_s2 (always fp32). */
+ * cout' = cin, same ksize, stride 1): dx = conv(dz, W'). flip = 0: operand of yolo_conv_dgrad_s2 in the same dtype
+ * (fp32: row-major W'; 16-bit: four tap-subset fragment streams, one per output parity class). */
 size_t yolo_packed_dgrad_bytes(int cout, int cin, int ksize, int flip, int dtype);
 int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, int dtype, void* stream);
 /* dx (n,2ho,2wo,cin) = transposed 3x3 stride-2 conv of dz (n,ho,wo,cout) [+ residual] */

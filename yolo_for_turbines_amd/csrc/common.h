@@ -135,6 +135,10 @@ int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, cons
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
 int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
+size_t h16_dgrad_s2_elems(int cout, int cin);
+int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtype, hipStream_t s);
+int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, const void* residual, int r_ld, int r_off, void* dx,
+                        int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, hipStream_t s);
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s);
 // wgrad_h16.hip (bf16 / fp16 weight gradient, transposing LDS reads)

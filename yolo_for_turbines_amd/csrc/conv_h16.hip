@@ -47,6 +47,7 @@ struct ConvHArgs {
     int act, out_mode, flags, nc5;
     int Ho, Wo;
     int first_wave, stagger;
+    int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
 };
 
 template <typename T> struct HTraits;
@@ -160,6 +161,91 @@ __device__ __forceinline__ void h_chunk(const ConvHArgs& p, const HCtx<T, TN>& c
     }
 }
 
+// ---- tap subsets (stride-2 input gradient, see dgrad_s2_h16 below) ------------------------------------
+// MASK selects taps of the 3x3 window (bit kh*3+kw); the K loop runs over the set bits only. The ring slot
+// must be compile-time, so three chunks are unrolled (R = running K-step index mod 3).
+constexpr int mask_count(int m) { int n = 0; for (int b = 0; b < 9; ++b) n += (m >> b) & 1; return n; }
+constexpr int mask_nth(int m, int n) { for (int b = 0; b < 9; ++b) if ((m >> b) & 1) { if (n == 0) return b; --n; } return 0; }
+
+template <typename T, int TN, int MASK, int TI, int R>
+__device__ __forceinline__ void h_kstep_m(const ConvHArgs& p, const HCtx<T, TN>& c, int chunk, char* patch,
+                                          u32x4 (&ring)[3][2][TN], u32x4 (&stage)[H_NI], u32x4 (&af)[2][2],
+                                          f32x16 (&acc)[2][TN], int tid) {
+    typedef typename HTraits<T>::vec vec;
+    constexpr int NT = mask_count(MASK);
+    constexpr int PF_T = NT > 2 ? NT - 2 : 0;
+    constexpr int CUR = R % 3, NXT2 = (R + 2) % 3;
+    constexpr int TAP0 = mask_nth(MASK, 0);
+    const int kt = chunk * NT + TI;
+    const int kta = kt + 2 < c.KT ? kt + 2 : c.KT - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            ring[NXT2][s][j] = *reinterpret_cast<const u32x4*>(c.wfrag[j] + ((size_t)kta * 2 + s) * 512);
+    if (TI == PF_T) {
+        const int cn = chunk + 1 < p.nchunks ? chunk + 1 : chunk;
+        const int coff = p.x_off + cn * 32 + (tid & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < H_NI; ++i) {
+            const int px = c.pix[i] < 0 ? 0 : c.pix[i];
+            stage[i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 an[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) an[i][s] = af[i][s];
+    if (TI + 1 < NT) {                                   // a_off already points at the first tap of the set
+        constexpr int NTAP = mask_nth(MASK, TI + 1 < NT ? TI + 1 : 0);
+        constexpr int dkh = NTAP / 3 - TAP0 / 3, dkw = NTAP % 3 - TAP0 % 3;
+        const char* Ab_next = patch + (chunk & 1) * (p.patch_cap * H_PIX_BYTES) + (dkh * p.PC + dkw) * H_PIX_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) an[i][s] = *reinterpret_cast<const u32x4*>(Ab_next + c.a_off[i] + s * 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const vec b = __builtin_bit_cast(vec, ring[CUR][s][j]);
+            acc[0][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[0][s]), b, acc[0][j]);
+            acc[1][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[1][s]), b, acc[1][j]);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[i][s] = an[i][s];
+    if (TI == NT - 1) {
+        char* dst = patch + ((chunk + 1) & 1) * (p.patch_cap * H_PIX_BYTES) + (tid >> 2) * H_PIX_BYTES + (tid & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < H_NI; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if ((tid >> 2) + 64 * i < p.patch_cap) *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
+        }
+        __syncthreads();
+        const char* An = patch + ((chunk + 1) & 1) * (p.patch_cap * H_PIX_BYTES);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(An + c.a_off[i] + s * 32);
+    }
+}
+
+template <typename T, int TN, int MASK, int CC, int TI>
+__device__ __forceinline__ void h_chunk_m(const ConvHArgs& p, const HCtx<T, TN>& c, int chunk, char* patch,
+                                          u32x4 (&ring)[3][2][TN], u32x4 (&stage)[H_NI], u32x4 (&af)[2][2],
+                                          f32x16 (&acc)[2][TN], int tid) {
+    constexpr int NT = mask_count(MASK);
+    if constexpr (TI < NT) {
+        h_kstep_m<T, TN, MASK, TI, (CC * NT + TI) % 3>(p, c, chunk, patch, ring, stage, af, acc, tid);
+        h_chunk_m<T, TN, MASK, CC, TI + 1>(p, c, chunk, patch, ring, stage, af, acc, tid);
+    }
+}
+
 // 1x1: one tap per chunk -> unroll three chunks so the ring index stays compile-time
 template <typename T, int TN, int R>
 __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN>& c, int chunk, char* patch,
@@ -205,9 +291,10 @@ __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN
         for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(An + c.a_off[i] + s * 32);
 }
 
-template <typename T, int KS, int STRIDE, int BN>
+template <typename T, int KS, int STRIDE, int BN, int MASK = 0>
 __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
     constexpr int TN = BN / 64;
+    static_assert(MASK == 0 || (KS == 3 && STRIDE == 1), "tap subsets are defined on the 3x3 stride-1 window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* patch = smem_raw;                                             // [2][patch_cap][80 B]
     int* mtab = reinterpret_cast<int*>(patch + 2 * p.patch_cap * H_PIX_BYTES);
@@ -270,11 +357,21 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
         const int g = g0 + r;
         const bool ok = pp < p.TH * p.TW && g <= g_last && c0 + cc < p.W;
         c.a_off[i] = (ok ? ((vrow(g) - v0) * p.PC + STRIDE * cc) * H_PIX_BYTES : 0) + 16 * fh;
+        if (MASK) c.a_off[i] += ((mask_nth(MASK, 0) / 3) * p.PC + mask_nth(MASK, 0) % 3) * H_PIX_BYTES;
     }
     if (tid < 128) {
         const int r = tid / p.TW, cc = tid - r * p.TW;
         const int g = g0 + r;
-        mtab[tid] = (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) ? g * p.W + c0 + cc : -1;
+        int m = -1;
+        if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
+            if (MASK) {                               // parity class: dx pixel (2r + ph, 2c + pw) of image n
+                const int n = g / p.H, rr = g - n * p.H;
+                m = (n * 2 * p.H + 2 * rr + p.cls_ph) * (2 * p.W) + 2 * (c0 + cc) + p.cls_pw;
+            } else {
+                m = g * p.W + c0 + cc;
+            }
+        }
+        mtab[tid] = m;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -321,7 +418,16 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(patch + c.a_off[i] + s * 32);
 
-    if constexpr (KS == 3) {
+    if constexpr (MASK != 0) {
+        int chunk = 0;
+        for (; chunk + 3 <= p.nchunks; chunk += 3) {
+            h_chunk_m<T, TN, MASK, 0, 0>(p, c, chunk, patch, ring, stage, af, acc, tid);
+            h_chunk_m<T, TN, MASK, 1, 0>(p, c, chunk + 1, patch, ring, stage, af, acc, tid);
+            h_chunk_m<T, TN, MASK, 2, 0>(p, c, chunk + 2, patch, ring, stage, af, acc, tid);
+        }
+        if (chunk < p.nchunks) h_chunk_m<T, TN, MASK, 0, 0>(p, c, chunk, patch, ring, stage, af, acc, tid);
+        if (chunk + 1 < p.nchunks) h_chunk_m<T, TN, MASK, 1, 0>(p, c, chunk + 1, patch, ring, stage, af, acc, tid);
+    } else if constexpr (KS == 3) {
         for (int chunk = 0; chunk < p.nchunks; ++chunk) h_chunk<T, 3, TN, 0>(p, c, chunk, patch, ring, stage, af, acc, tid);
     } else {
         int chunk = 0;
@@ -348,8 +454,8 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
         {
             const int n = n_tile * BN + wn * (BN / 2) + j * 32 + frow;
             const bool nv = n < p.Cout;
-            const float sc = nv ? p.scale[n] : 0.f;
-            const float sh = nv ? p.shift[n] : 0.f;
+            const float sc = nv ? (MASK ? 1.f : p.scale[n]) : 0.f;       // gradient kernels: plain accumulation
+            const float sh = nv ? (MASK ? 0.f : p.shift[n]) : 0.f;
             float* dst = ost + wn * 32 + frow;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -506,6 +612,66 @@ int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int
     return check_launch("pack_dgrad_frag_h16");
 }
 
+// ---- stride-2 input gradient (transposed conv) as four stride-1 tap-subset convolutions over dz -------------
+//   dx[n, 2r+ph, 2c+pw, ci] = sum_{dh <= ph, dw <= pw, co} dz[n, r+dh, c+dw, co] * W[co, ci, ph+1-2dh, pw+1-2dw]
+// In the 3x3 window of the patch kernel (pad 1) the offset (dh, dw) is tap (1+dh, 1+dw): class (ph, pw) uses the
+// taps {1, 1+ph} x {1, 1+pw} — 1, 2, 2 and 4 of them, 9 in total, so no matrix work is spent on structural zeros.
+constexpr int cls_mask(int ph, int pw) {
+    int m = 0;
+    for (int dh = 0; dh <= ph; ++dh)
+        for (int dw = 0; dw <= pw; ++dw) m |= 1 << ((1 + dh) * 3 + 1 + dw);
+    return m;
+}
+static size_t cls_frag_elems(int cin, int cout, int cls) {       // N = cin (dx channels), K = cout
+    const int nt = mask_count(cls_mask(cls >> 1, cls & 1));
+    return (size_t)(round_up(cin, 128) / 32) * (cout / 32) * nt * 1024;
+}
+
+template <typename T>
+__global__ void pack_dgrad_s2_cls_h16(const float* __restrict__ w, unsigned short* __restrict__ wf, int cout, int cin, int ph, int pw,
+                                      int NT, int KT, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const int s = (int)((i >> 9) & 1);
+        const long long rest = i >> 10;
+        const int kt = (int)(rest % KT);
+        const int nt = (int)(rest / KT);
+        const int ci = nt * 32 + (lane & 31);
+        const int chunk = kt / NT, t = kt - chunk * NT;
+        const int dh = pw ? t / 2 : t, dw = pw ? t % 2 : 0;       // taps in window order: dh-major, dw-minor
+        const int kh = ph + 1 - 2 * dh, kw = pw + 1 - 2 * dw;
+        const int co = chunk * 32 + s * 16 + 8 * (lane >> 5) + e;
+        const float v = (ci < cin && co < cout) ? w[((size_t)co * cin + ci) * 9 + kh * 3 + kw] : 0.f;
+        wf[i] = HTraits<T>::from_f32(v);
+    }
+}
+
+size_t h16_dgrad_s2_elems(int cout, int cin) {
+    size_t n = 0;
+    for (int cls = 0; cls < 4; ++cls) n += cls_frag_elems(cin, cout, cls);
+    return n;
+}
+
+int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtype, hipStream_t s) {
+    unsigned short* dst = (unsigned short*)wf;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        const int NT = mask_count(cls_mask(ph, pw));
+        const long long total = (long long)cls_frag_elems(cin, cout, cls);
+        const int KT = (cout / 32) * NT;
+        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        if (dtype == YOLO_BF16)
+            hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<__bf16>, dim3(grid), dim3(256), 0, s, w_oihw, dst, cout, cin, ph, pw, NT, KT, total);
+        else
+            hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, dst, cout, cin, ph, pw, NT, KT, total);
+        const int rc = check_launch("pack_dgrad_s2_cls_h16");
+        if (rc) return rc;
+        dst += total;
+    }
+    return YOLO_OK;
+}
+
 static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax) {
     if (ks == 1) { *th = 1; *tw = 128; *prmax = 1; return; }
     double best = -1;
@@ -537,6 +703,68 @@ static int launch_h(ConvHArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
     hipLaunchKernelGGL((conv_patch_h16<T, KS, STRIDE, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16");
+}
+
+template <typename T, int BN, int MASK>
+static int launch_cls(ConvHArgs& a, hipStream_t s) {
+    a.tiles_n = ceil_div(a.Cout, BN);
+    const int tiles_r = ceil_div(a.rows_total, a.TH);
+    a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
+    a.first_wave = 2 * 256;
+    const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
+    a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
+    const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
+    hipLaunchKernelGGL((conv_patch_h16<T, 3, 1, BN, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
+    return check_launch("conv_patch_h16 (dgrad s2 class)");
+}
+
+template <typename T>
+static int dgrad_s2_classes(ConvHArgs& a, const unsigned short* wf, int cin, int cout, int bn, hipStream_t s) {
+    for (int cls = 0; cls < 4; ++cls) {
+        a.cls_ph = cls >> 1; a.cls_pw = cls & 1;
+        a.wf = wf;
+        a.KT = a.nchunks * mask_count(cls_mask(a.cls_ph, a.cls_pw));
+        int rc;
+        if (bn == 128) {
+            rc = cls == 0 ? launch_cls<T, 128, cls_mask(0, 0)>(a, s) : cls == 1 ? launch_cls<T, 128, cls_mask(0, 1)>(a, s)
+               : cls == 2 ? launch_cls<T, 128, cls_mask(1, 0)>(a, s) : launch_cls<T, 128, cls_mask(1, 1)>(a, s);
+        } else {
+            rc = cls == 0 ? launch_cls<T, 64, cls_mask(0, 0)>(a, s) : cls == 1 ? launch_cls<T, 64, cls_mask(0, 1)>(a, s)
+               : cls == 2 ? launch_cls<T, 64, cls_mask(1, 0)>(a, s) : launch_cls<T, 64, cls_mask(1, 1)>(a, s);
+        }
+        if (rc) return rc;
+        wf += cls_frag_elems(cin, cout, cls);
+    }
+    return YOLO_OK;
+}
+
+// dx (n, 2ho, 2wo, cin) [+ residual] from dz (n, ho, wo, cout), weights from h16_pack_dgrad_s2
+int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, const void* residual, int r_ld, int r_off, void* dx,
+                        int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, hipStream_t s) {
+    if (cout % 32) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2 (16-bit): cout %d must be a multiple of 32", cout);
+    if ((dz_ld & 7) || (dz_off & 7)) return fail(YOLO_ERR_ARG, "dgrad_s2 (16-bit): dz_ld/dz_off must be multiples of 8");
+    ConvHArgs a;
+    a.x = (const unsigned short*)dz; a.scale = nullptr; a.shift = nullptr;
+    a.res = (const unsigned short*)residual; a.y = dx; a.nan_flag = nullptr;
+    a.Cin = cout; a.Cout = cin;
+    a.x_ld = dz_ld; a.x_off = dz_off; a.y_ld = dx_ld; a.y_off = dx_off; a.r_ld = r_ld; a.r_off = r_off;
+    a.Hin = ho; a.Win = wo; a.Ho = ho; a.Wo = wo;
+    const long long M = (long long)n * ho * wo;
+    if (M * 4 > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2: too many pixels");
+    int prmax = 1;
+    a.H = ho; a.W = wo; a.rows_total = n * ho;
+    pick_tile_h(ho, ho, wo, 3, 1, &a.TH, &a.TW, &prmax);
+    a.PC = a.TW + 2;
+    a.patch_cap = round_up(prmax * a.PC, 64);
+    if (a.patch_cap < 224) a.patch_cap = 224;
+    if (a.patch_cap > H_PATCH_CAP) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2 (16-bit): patch too large");
+    a.tiles_w = ceil_div(a.W, a.TW);
+    a.nchunks = cout / 32;
+    a.act = YOLO_ACT_NONE; a.out_mode = YOLO_OUT_NHWC; a.flags = residual ? YOLO_FLAG_RESIDUAL : 0;
+    a.nc5 = 1;
+    const int bn = (cin > 64 && ho <= 52) ? 128 : 64;
+    if (dtype == YOLO_BF16) return dgrad_s2_classes<__bf16>(a, (const unsigned short*)wf, cin, cout, bn, s);
+    return dgrad_s2_classes<_Float16>(a, (const unsigned short*)wf, cin, cout, bn, s);
 }
 
 template <typename T>

@@ -211,12 +211,14 @@ size_t yolo_packed_dgrad_bytes(int cout, int cin, int ksize, int flip, int dtype
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const int coutp = round_up(cout, 32);
     if (flip && dtype != YOLO_F32) return h16_frag_elems(cin, coutp, ksize) * 2;
+    if (!flip && dtype != YOLO_F32) return (ksize == 3 && cout % 32 == 0) ? h16_dgrad_s2_elems(cout, cin) * 2 : 0;
     return (v0_packed_elems(cin, coutp, ksize) + v2_frag_elems(cin, coutp, ksize)) * sizeof(float);
 }
 
 int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, int dtype, void* stream) {
     if (!w_oihw || !w_packed || !yolo_packed_dgrad_bytes(cout, cin, ksize, flip, dtype)) return fail(YOLO_ERR_ARG, "pack_weights_dgrad: bad arguments");
     if (flip && dtype != YOLO_F32) return h16_pack_dgrad(w_oihw, w_packed, cout, cin, ksize, dtype, (hipStream_t)stream);
+    if (!flip && dtype != YOLO_F32) return h16_pack_dgrad_s2(w_oihw, w_packed, cout, cin, dtype, (hipStream_t)stream);
     const int coutp = round_up(cout, 32);
     const int kpad = kpad_of(coutp, ksize);
     const long long total = (long long)v0_packed_elems(cin, coutp, ksize);
@@ -237,6 +239,9 @@ int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int c
 int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_packed, const void* residual, int r_ld, int r_off,
                        void* dx, int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, void* stream) {
     if (!dz || !w_packed || !dx) return fail(YOLO_ERR_ARG, "dgrad_s2: null pointer");
+    if (dtype == YOLO_BF16 || dtype == YOLO_F16)
+        return dgrad_s2_h16_launch(dz, dz_ld, dz_off, w_packed, residual, r_ld, r_off, dx, dx_ld, dx_off, n, ho, wo, cin, cout, dtype,
+                                   (hipStream_t)stream);
     if (n <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0 || cout % 32) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2: cout %% 32 != 0");
     if ((dz_ld & 3) || (dz_off & 3)) return fail(YOLO_ERR_ARG, "dgrad_s2: dz_ld/dz_off must be multiples of 4");
     DgradS2Args a;
