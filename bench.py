@@ -186,23 +186,30 @@ def main():
         tg = [torch.from_numpy(t).to(device) for t in gi.synth_targets(args.batch, args.size, args.train_classes, anchors, 3 + rank)]
         lf = yt.YOLOLoss()
         opt = torch.optim.SGD(tm.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
-
-        def train_step():                               # train.py:41-69: zero_grad, forward, 3 x loss, backward, SGD
-            opt.zero_grad(set_to_none=True)
-            preds = tm(x)
-            loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
-            loss.backward()
-            opt.step()
-
-        t_el = ydist.timed_steps(train_step, args.train_steps, 2, dist, device)
-        log(f"train leg: {t_el:.3f} s for {args.train_steps} steps")
         n_par = sum(p.numel() for p in tm.parameters())
-        train = {"metric": "images/sec at 416x416 (fwd+bwd)", "value": round(args.batch * world * args.train_steps / t_el, 2),
-                 "unit": "images/s", "ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps,
-                 "per_gpu_batch": args.batch, "num_classes": args.train_classes, "dtype": "f32",
-                 "step": "zero_grad + forward(train-mode BN) + 3 x YOLOLoss + backward + SGD",
-                 "parallelism": f"dp{world}" + (f": bucketed RCCL all-reduce of {n_par * 4 / 1e6:.1f} MB fp32 gradients" if world > 1 else ""),
-                 "algorithmic_tflops": round(3 * 65.297 * (args.size / 416.0) ** 2 * args.batch * world * args.train_steps / t_el / 1e3, 2)}
+
+        def train_leg(autocast_dtype):
+            def train_step():                           # train.py:41-69: zero_grad, autocast forward, 3 x loss, backward, SGD
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
+                    preds = tm(x)
+                loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+                loss.backward()
+                opt.step()
+            t_el = ydist.timed_steps(train_step, args.train_steps, 2, dist, device)
+            name = "f32" if autocast_dtype is None else "bf16"
+            log(f"train leg ({name}): {t_el:.3f} s for {args.train_steps} steps")
+            return {"metric": "images/sec at 416x416 (fwd+bwd)", "value": round(args.batch * world * args.train_steps / t_el, 2),
+                    "unit": "images/s", "ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps,
+                    "per_gpu_batch": args.batch, "num_classes": args.train_classes, "dtype": name,
+                    "step": "zero_grad + forward(train-mode BN) + 3 x YOLOLoss + backward + SGD",
+                    "parallelism": f"dp{world}" + (f": bucketed RCCL all-reduce of {n_par * 4 / 1e6:.1f} MB fp32 gradients" if world > 1 else ""),
+                    "algorithmic_tflops": round(3 * 65.297 * (args.size / 416.0) ** 2 * args.batch * world * args.train_steps / t_el / 1e3, 2)}
+
+        train = train_leg(None)
+        # BASELINE configs[3] arithmetic: the same step under torch.autocast(bf16) (train.py:53) -> 16-bit kernels for
+        # activations and activation gradients, fp32 master weights / statistics / parameter gradients
+        train["bf16_autocast"] = train_leg(torch.bfloat16)
         del tm, opt
         torch.cuda.empty_cache()
 

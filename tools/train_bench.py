@@ -12,6 +12,7 @@ ap.add_argument("--size", type=int, default=416)
 ap.add_argument("--classes", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
+ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 from bench import seeded_model
@@ -44,6 +45,38 @@ def step(timing=None):
 
 for _ in range(2):
     step()
+if a.graph:
+    # whole-step capture: forward(train) + loss + backward + SGD as ONE graph launch (no per-kernel launch cost).
+    # Needs the per-forward NaN guard's host sync off and capturable optimizer state.
+    m._engine.nan_check = False
+    opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            preds = m(x)
+            loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+            loss.backward()
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        preds = m(x)
+        gloss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+        gloss.backward()
+        opt.step()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"{a.dtype} B={a.batch} S={a.size} nc={a.classes} [graph]: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} img/s | loss {float(gloss):.3f}")
+    sys.exit(0)
 t = []
 t0 = time.perf_counter()
 for _ in range(a.steps):
