@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_mi355x.so")
+LIB_PATH = os.environ.get("YOLO_MI355X_LIB") or os.path.join(_HERE, "libyolo_mi355x.so")
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_MISH = 0, 1, 2

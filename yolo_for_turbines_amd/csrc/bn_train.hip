@@ -21,25 +21,6 @@
 
 namespace yolo {
 
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == YOLO_ACT_LEAKY) return u > 0.f ? u : u * 0.1f;
-    if (act == YOLO_ACT_MISH) {
-        const float sp = u > 20.f ? u : log1pf(expf(u));
-        return u * tanhf(sp);
-    }
-    return u;
-}
-
-__device__ __forceinline__ float act_grad(float u, int act) {
-    if (act == YOLO_ACT_LEAKY) return u > 0.f ? 1.f : 0.1f;
-    if (act == YOLO_ACT_MISH) {                      // d/du [u * tanh(softplus(u))]
-        const float sp = u > 20.f ? u : log1pf(expf(u));
-        const float t = tanhf(sp);
-        const float sg = 1.f / (1.f + expf(-u));
-        return t + u * (1.f - t * t) * sg;
-    }
-    return 1.f;
-}
 
 // VN consecutive per-channel parameters (fp32) as 16-byte loads
 template <int VN>
@@ -191,13 +172,13 @@ __global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, 
 
 // y = act((z - mean)*scale + shift) [+ residual], one 16-byte vector per thread and iteration, same output
 // modes as the conv epilogue
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const typename Elt<T>::S* __restrict__ res, int r_ld, int r_off,
                                                          typename Elt<T>::S* __restrict__ y, int y_ld, int y_off, long long m, int c,
-                                                         int Ho, int Wo, int act, int out_mode, int* nan_flag) {
+                                                         int Ho, int Wo, int out_mode, int* nan_flag) {
     constexpr int VN = Vec16<T>::VN;
     const int cv = c / VN;
     const long long total = m * cv;
@@ -215,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
             for (int e = 0; e < VN; ++e) mu[e] = 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < VN; ++e) v[e] = act_fwd((x[e] - mu[e]) * sc[e] + sh[e], act);
+        for (int e = 0; e < VN; ++e) v[e] = act_c<ACT>((x[e] - mu[e]) * sc[e] + sh[e]);
         if (res) {
             float r[VN];
             Vec16<T>::ld(res + (size_t)p * r_ld + r_off + ch, r);
@@ -243,12 +224,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
 }
 
 // partial[blk][c][2]: sum du, sum du*zhat.  mean == nullptr: bare conv (du = dy, only sum du is used)
-template <typename T, bool LONG>
+template <typename T, bool LONG, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
                                                       const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      int m, int c, int act, int pix_per_block, double* __restrict__ partial) {
+                                                      int m, int c, int pix_per_block, double* __restrict__ partial) {
     constexpr int VN = Vec16<T>::VN;
     const int cv = c / VN;
     const RedGeom g = red_geom(cv);
@@ -275,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* 
             auto accum = [&](const float (&d)[VN], const float (&x)[VN]) {
 #pragma unroll
                 for (int e = 0; e < VN; ++e) {
-                    const float du = mean ? d[e] * act_grad((x[e] - mu[e]) * sc[e] + sh[e], act) : d[e];
+                    const float du = mean ? d[e] * act_grad_c<ACT>((x[e] - mu[e]) * sc[e] + sh[e]) : d[e];
                     fs[e] += du;
                     fq[e] += du * ((x[e] - mu[e]) * is[e]);
                 }
@@ -338,13 +319,13 @@ __global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, in
     coef[2 * c + ch] = (float)(q / m);                  // mean(du * zhat)
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
                                                     const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ coef, typename Elt<T>::S* __restrict__ dz, int dz_ld,
-                                                    int dz_off, long long m, int c, int act) {
+                                                    int dz_off, long long m, int c) {
     constexpr int VN = Vec16<T>::VN;
     const int cv = c / VN;
     const long long total = m * cv;
@@ -364,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             const float xc = x[e] - mu[e];
-            const float du = d[e] * act_grad(xc * sc[e] + sh[e], act);
+            const float du = d[e] * act_grad_c<ACT>(xc * sc[e] + sh[e]);
             o[e] = k0[e] * (du - k1[e] - xc * is[e] * k2[e]);
         }
         Vec16<T>::st(dz + (size_t)p * dz_ld + dz_off + ch, o);
@@ -465,9 +446,10 @@ int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const
     if (out_mode != YOLO_OUT_NHWC && out_mode != YOLO_OUT_UPSAMPLE2X) return fail(YOLO_ERR_ARG, "bn_act_fwd: out_mode");
     const long long m = (long long)n * h * w;
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_fwd",
-        hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(m * (c / vn))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z, z_ld,
-                           z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, m, c, h, w, act,
-                           out_mode, nan_flag));
+        YOLO_SWITCH_ACT(act,
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(ew_grid(m * (c / vn))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z,
+                               z_ld, z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, m, c, h, w,
+                               out_mode, nan_flag)));
     return check_launch("bn_act_fwd");
 }
 
@@ -488,18 +470,20 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
     double* part = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)nblk * c * 2 * sizeof(double));
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
-        if (lr) hipLaunchKernelGGL((bn_bwd_partial<T, true>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld,
-                                   z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part);
-        else hipLaunchKernelGGL((bn_bwd_partial<T, false>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off, (const Elt<T>::S*)z, z_ld,
-                                z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, act, ppb, part));
+        YOLO_SWITCH_ACT(act,
+            if (lr) hipLaunchKernelGGL((bn_bwd_partial<T, true, ACT>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                                       (const Elt<T>::S*)z, z_ld, z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, ppb, part);
+            else hipLaunchKernelGGL((bn_bwd_partial<T, false, ACT>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                                    (const Elt<T>::S*)z, z_ld, z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, ppb, part)));
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
     rc = check_launch("bn_bwd_finalize");
     if (rc || !gamma) return rc;
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
-        hipLaunchKernelGGL(bn_bwd_apply<T>, dim3(ew_grid((long long)m * (c / vn))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
-                           (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, (long long)m, c, act));
+        YOLO_SWITCH_ACT(act,
+            hipLaunchKernelGGL((bn_bwd_apply<T, ACT>), dim3(ew_grid((long long)m * (c / vn))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                               (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, (long long)m, c)));
     return check_launch("bn_bwd_apply");
 }
 

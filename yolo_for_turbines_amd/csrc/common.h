@@ -71,6 +71,48 @@ template <> struct Elt<_Float16> {
     static __device__ __forceinline__ void st(S* p, float v) { *reinterpret_cast<_Float16*>(p) = (_Float16)v; }
 };
 
+// ---- activations: compile-time selected (a run-time `act` inside an unrolled epilogue loop made the compiler
+// inline libm's tanhf/log1pf/expf once per element and branch per element: 16k-instruction epilogues that
+// thrashed the instruction cache and cost more than the matrix work of a 16-bit block).
+// Mish(x) = x * tanh(softplus(x)) = x * n / (n + 2) with n = e^x (e^x + 2): one v_exp_f32 + one v_rcp_f32,
+// no cancellation for x -> -inf (n ~ 2 e^x), identity for x > 20. Derivative: with t = n/(n+2),
+// s = sigmoid(x) = e/(1+e):  d/dx = t + x (1 - t^2) s.
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+    if constexpr (ACT == YOLO_ACT_LEAKY) {
+        return v > 0.f ? v : v * 0.1f;
+    } else if constexpr (ACT == YOLO_ACT_MISH) {
+        const float e = __expf(v < 20.f ? v : 20.f);
+        const float n = e * (e + 2.f);
+        const float m = v * (n * __builtin_amdgcn_rcpf(n + 2.f));
+        return v > 20.f ? v : m;
+    } else {
+        return v;
+    }
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(float u) {
+    if constexpr (ACT == YOLO_ACT_LEAKY) {
+        return u > 0.f ? 1.f : 0.1f;
+    } else if constexpr (ACT == YOLO_ACT_MISH) {
+        const float e = __expf(u < 20.f ? u : 20.f);
+        const float n = e * (e + 2.f);
+        const float t = n * __builtin_amdgcn_rcpf(n + 2.f);
+        const float sg = e * __builtin_amdgcn_rcpf(1.f + e);
+        const float g = t + u * (1.f - t * t) * sg;
+        return u > 20.f ? 1.f : g;
+    } else {
+        return 1.f;
+    }
+}
+// run `body` (device or host code) with the constant ACT bound to the run-time activation code
+#define YOLO_SWITCH_ACT(act, ...)                                                          \
+    switch (act) {                                                                          \
+    case YOLO_ACT_LEAKY: { constexpr int ACT = YOLO_ACT_LEAKY; __VA_ARGS__; } break;       \
+    case YOLO_ACT_MISH: { constexpr int ACT = YOLO_ACT_MISH; __VA_ARGS__; } break;         \
+    default: { constexpr int ACT = YOLO_ACT_NONE; __VA_ARGS__; } break;                    \
+    }
+
 // 16-byte vectors for the HBM-bound passes: VN elements (4 fp32 / 8 halfs) per load
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

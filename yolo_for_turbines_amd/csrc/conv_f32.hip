@@ -44,14 +44,6 @@ struct ConvArgs {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;   // padded row length (floats)
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == YOLO_ACT_LEAKY) return v > 0.f ? v : v * 0.1f;               // nn.LeakyReLU(0.1)
-    if (act == YOLO_ACT_MISH) {                                             // x * tanh(softplus(x))
-        float sp = v > 20.f ? v : log1pf(__expf(v));
-        return v * tanhf(sp);
-    }
-    return v;
-}
 
 template <int BM, int BN, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
@@ -186,14 +178,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             head_a = n / p.nc5;
             head_k = n - head_a * p.nc5;
         }
+        YOLO_SWITCH_ACT(p.act,                          // activation chosen once, outside the element loops
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = act_c<ACT>(acc[i][j][r] * sc + sh);)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= p.M || !nv) continue;
-                float v = acc[i][j][r] * sc + sh;
-                v = act_apply(v, p.act);
+                float v = acc[i][j][r];
                 if (has_res) v += p.res[(size_t)m * p.r_ld + p.r_off + n];
                 if (nan_chk && v != v) saw_nan = true;
                 if (p.out_mode == YOLO_OUT_NHWC) {

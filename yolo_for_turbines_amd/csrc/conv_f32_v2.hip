@@ -49,14 +49,6 @@ struct Conv2Args {
 #endif
 };
 
-__device__ __forceinline__ float act_apply2(float v, int act) {
-    if (act == YOLO_ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
-    if (act == YOLO_ACT_MISH) {
-        float sp = v > 20.f ? v : log1pf(__expf(v));
-        return v * tanhf(sp);
-    }
-    return v;
-}
 
 template <int KS, int TN>
 struct V2Ctx {
@@ -310,13 +302,12 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
             const float sc = nv ? p.scale[n] : 0.f;
             const float sh = nv ? p.shift[n] : 0.f;
             float* dst = ost + wn * 32 + frow;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    dst[row * OLD] = act_apply2(acc[i][j][r] * sc + sh, p.act);
-                }
+            YOLO_SWITCH_ACT(p.act,
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc + sh);
+                    })
         }
         __syncthreads();
         if (vec_ok) {

@@ -64,15 +64,6 @@ template <> struct HTraits<_Float16> {
     static __device__ __forceinline__ unsigned short from_f32(float f) { _Float16 h = (_Float16)f; return *reinterpret_cast<unsigned short*>(&h); }
 };
 
-__device__ __forceinline__ float act_h(float v, int act) {
-    if (act == YOLO_ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
-    if (act == YOLO_ACT_MISH) {
-        float sp = v > 20.f ? v : log1pf(__expf(v));
-        return v * tanhf(sp);
-    }
-    return v;
-}
-
 template <typename T, int TN>
 struct HCtx {
     const unsigned short* wfrag[TN];
@@ -457,13 +448,12 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
             const float sc = nv ? (MASK ? 1.f : p.scale[n]) : 0.f;       // gradient kernels: plain accumulation
             const float sh = nv ? (MASK ? 0.f : p.shift[n]) : 0.f;
             float* dst = ost + wn * 32 + frow;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    dst[row * OLD] = act_h(acc[i][j][r] * sc + sh, p.act);
-                }
+            YOLO_SWITCH_ACT(p.act,
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc + sh);
+                    })
         }
         __syncthreads();
         if (vec_ok) {

@@ -72,14 +72,12 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
     }
     if (bad_in) atomicOr(nan_flag, 1);                    // NaN in the INPUT tensor (model.py:175)
     bool bad = false;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-        float t = acc[co] * scale[co] + shift[co];
-        if (act == YOLO_ACT_LEAKY) t = t > 0.f ? t : t * 0.1f;
-        else if (act == YOLO_ACT_MISH) { float sp = t > 20.f ? t : log1pf(__expf(t)); t = t * tanhf(sp); }
-        bad |= (t != t);
-        acc[co] = t;
-    }
+    YOLO_SWITCH_ACT(act,
+        _Pragma("unroll") for (int co = 0; co < COUT; ++co) {
+            const float t = act_c<ACT>(acc[co] * scale[co] + shift[co]);
+            bad |= (t != t);
+            acc[co] = t;
+        })
     if (dtype == YOLO_F32) {
         float* dst = y + (size_t)p * y_ld + y_off;
 #pragma unroll
