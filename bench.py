@@ -184,27 +184,65 @@ def main():
         grids = [args.size // 32, args.size // 16, args.size // 8]
         sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(device)
         tg = [torch.from_numpy(t).to(device) for t in gi.synth_targets(args.batch, args.size, args.train_classes, anchors, 3 + rank)]
-        lf = yt.YOLOLoss()
         opt = torch.optim.SGD(tm.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
         n_par = sum(p.numel() for p in tm.parameters())
+        step_desc = "zero_grad + forward(train-mode BN) + 3 x per-scale loss + backward + SGD"
 
-        def train_leg(autocast_dtype):
-            def train_step():                           # train.py:41-69: zero_grad, autocast forward, 3 x loss, backward, SGD
+        def make_step(lf, autocast_dtype):              # train.py:41-69: zero_grad, autocast forward, 3 x loss, backward, SGD
+            def train_step():
                 opt.zero_grad(set_to_none=True)
                 with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
                     preds = tm(x)
                 loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
                 loss.backward()
                 opt.step()
-            t_el = ydist.timed_steps(train_step, args.train_steps, 2, dist, device)
-            name = "f32" if autocast_dtype is None else "bf16"
-            log(f"train leg ({name}): {t_el:.3f} s for {args.train_steps} steps")
+            return train_step
+
+        def entry(t_el, name, loss_name):
             return {"metric": "images/sec at 416x416 (fwd+bwd)", "value": round(args.batch * world * args.train_steps / t_el, 2),
                     "unit": "images/s", "ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps,
-                    "per_gpu_batch": args.batch, "num_classes": args.train_classes, "dtype": name,
-                    "step": "zero_grad + forward(train-mode BN) + 3 x YOLOLoss + backward + SGD",
+                    "per_gpu_batch": args.batch, "num_classes": args.train_classes, "dtype": name, "step": step_desc, "loss": loss_name,
                     "parallelism": f"dp{world}" + (f": bucketed RCCL all-reduce of {n_par * 4 / 1e6:.1f} MB fp32 gradients" if world > 1 else ""),
                     "algorithmic_tflops": round(3 * 65.297 * (args.size / 416.0) ** 2 * args.batch * world * args.train_steps / t_el / 1e3, 2)}
+
+        def graph_leg(autocast_dtype):                  # the same step captured ONCE into a HIP graph and replayed
+            lf = yt.FusedYOLOLoss()
+            step = make_step(lf, autocast_dtype)
+            tm._engine.nan_check = False                # the per-forward NaN guard is a host sync
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            gph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(gph):
+                with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
+                    preds = tm(x)
+                loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+                loss.backward()
+                opt.step()
+            t_el = ydist.timed_steps(gph.replay, args.train_steps, 2, dist, device)
+            tm._engine.nan_check = True
+            del gph
+            return t_el
+
+        def train_leg(autocast_dtype):
+            name = "f32" if autocast_dtype is None else "bf16"
+            t_f = ydist.timed_steps(make_step(yt.FusedYOLOLoss(), autocast_dtype), args.train_steps, 2, dist, device)
+            log(f"train leg ({name}, fused loss kernels): {t_f:.3f} s for {args.train_steps} steps")
+            e = entry(t_f, name, "FusedYOLOLoss (3 HIP kernels per scale; same values/gradients as loss.py:29-81)")
+            t_p = ydist.timed_steps(make_step(yt.YOLOLoss(), autocast_dtype), args.train_steps, 2, dist, device)
+            e["with_pytorch_loss"] = entry(t_p, name, "YOLOLoss (the reference's boolean-mask PyTorch ops)")
+            if world == 1:
+                try:
+                    t_g = graph_leg(autocast_dtype)
+                    e["hip_graph"] = entry(t_g, name, "FusedYOLOLoss; whole step replayed as one HIP graph")
+                except Exception as ex:                 # capture is an optimisation, never the measured default
+                    log(f"graph capture skipped: {ex!r}")
+                    torch.cuda.synchronize()
+            return e
 
         train = train_leg(None)
         # BASELINE configs[3] arithmetic: the same step under torch.autocast(bf16) (train.py:53) -> 16-bit kernels for

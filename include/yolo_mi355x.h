@@ -170,6 +170,19 @@ int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_pack
 /* upstream gradient in the head layout (B,3,g,g,D) fp32, any strides -> NHWC (B,g,g,ld) in dtype, channel a*D+k, pads 0 */
 int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream);
 
+/* ---- fused per-scale loss (optional replacement of YOLOLoss.forward, loss.py:29-81) -------- */
+/* pred (B,3,g,g,5+nc) fp32 through element strides; target (B,3,g,g,6) fp32 contiguous
+ * [x_cell,y_cell,w_cells,h_cells,obj in {1,0,-1},class]; anchors (3,2) in grid units.
+ * losses4 = [5*box, 1*object, 0.5*noobj, 1*class] (each a mean over the selected cells of this call, as in
+ * the reference), counts2 = [n_obj, n_noobj] for the backward. Deterministic (fixed-order fp64 sums), no host
+ * dependence (graph-capturable), and — unlike the reference — no in-place mutation of pred / target. */
+size_t yolo_loss_workspace_bytes(int b, int g);
+int yolo_loss_fwd(const float* pred, const int64_t* strides5, const float* target, const float* anchors_3x2, int b, int g, int nc,
+                  float* losses4, float* counts2, void* workspace, size_t workspace_bytes, void* stream);
+/* dpred (B,3,g,g,5+nc) contiguous = sum_k grad_losses4[k] * d losses4[k] / d pred */
+int yolo_loss_bwd(const float* pred, const int64_t* strides5, const float* target, const float* anchors_3x2, int b, int g, int nc,
+                  const float* counts2, const float* grad_losses4, float* dpred, void* stream);
+
 /* ---- post-processing ------------------------------------------------------------------- */
 /* Replaces cells_to_boxes (utils.py:86-148) for one scale.
  * pred: (B,3,g,g,5+nc) fp32 addressed through element strides s[5] (so the reference's permuted

@@ -652,3 +652,50 @@ def test_wgrad_16bit_kernel_vs_fp64(yt, case, dtype):
     got = dw.cpu().double()
     err = float((got - want).abs().max() / want.abs().max())
     assert err < 2e-5, f"{case} {dtype}: rel err {err}"
+
+
+# ------------------------------------------------------------- fused loss kernels (loss.py:29-81)
+@pytest.mark.parametrize("nc,S,B", [(2, 96, 4), (80, 64, 2), (2, 416, 2)])
+def test_fused_loss_values_and_gradients_vs_oracle(yt, nc, S, B):
+    """FusedYOLOLoss (3 HIP kernels per scale) against the oracle restatement of the reference loss under
+    CPU autograd: the four weighted parts per scale and dL/dpred for every scale."""
+    from oracle import loss as oloss
+    anchors = gi.TRAIN_CASE["anchors"]
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(B, S, nc, anchors, 77)]
+    grids = [S // 32, S // 16, S // 8]
+    sa = torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)
+    rng = np.random.Generator(np.random.PCG64(5))
+    fl = yt.FusedYOLOLoss()
+    for i, g in enumerate(grids):
+        p_cpu = torch.from_numpy(rng.standard_normal((B, 3, g, g, 5 + nc), dtype=np.float32)).requires_grad_(True)
+        w = torch.tensor([1.0, 0.7, 1.3, 0.9])
+        ref = torch.stack(oloss.yolo_loss(p_cpu * 1.0, tg[i].clone(), sa[i]))
+        (ref * w).sum().backward()
+        p_gpu = p_cpu.detach().cuda().requires_grad_(True)
+        t_gpu = tg[i].clone().cuda()
+        t_before = t_gpu.clone()
+        got = torch.stack(fl(p_gpu, t_gpu, sa[i].cuda()))
+        (got * w.cuda()).sum().backward()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+        gref = p_cpu.grad
+        err = float((p_gpu.grad.cpu() - gref).abs().max() / gref.abs().max())
+        assert err < 2e-5, f"scale {i}: grad rel err {err}"
+        assert torch.equal(t_gpu, t_before) and torch.equal(p_gpu.detach().cpu(), p_cpu.detach())     # no side effects
+
+
+def test_fused_loss_reference_view_and_empty_object_set(yt):
+    """The reference's permuted prediction view (non-contiguous strides) and a batch without any object."""
+    from oracle import loss as oloss
+    nc, g, B = 3, 7, 2
+    rng = np.random.Generator(np.random.PCG64(9))
+    raw = torch.from_numpy(rng.standard_normal((B, 3, 5 + nc, g, g), dtype=np.float32))
+    view_cpu = raw.permute(0, 1, 3, 4, 2)
+    t = torch.zeros((B, 3, g, g, 6))
+    t[0, 1, 2, 3] = torch.tensor([0.4, 0.6, 1.5, 2.0, 1.0, 2.0])
+    t[1, 0, 5, 5, 4] = -1.0
+    anc = torch.tensor([[1.0, 2.0], [2.5, 1.5], [4.0, 3.0]])
+    fl = yt.FusedYOLOLoss()
+    for tt in (t, torch.zeros_like(t)):
+        ref = torch.stack([torch.as_tensor(v) for v in oloss.yolo_loss(view_cpu.clone(), tt.clone(), anc)])
+        got = torch.stack(fl(raw.cuda().permute(0, 1, 3, 4, 2), tt.cuda(), anc.cuda()))
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-7)

@@ -12,6 +12,7 @@ ap.add_argument("--size", type=int, default=416)
 ap.add_argument("--classes", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
+ap.add_argument("--fused-loss", action="store_true", help="FusedYOLOLoss (3 HIP kernels per scale) instead of the PyTorch loss")
 ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -23,7 +24,7 @@ grids = [a.size // 32, a.size // 16, a.size // 8]
 sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(dev)
 x = torch.rand(a.batch, 3, a.size, a.size, device=dev)
 tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(a.batch, a.size, a.classes, anchors, 3)]
-lf = yt.YOLOLoss()
+lf = yt.FusedYOLOLoss() if (a.fused_loss or a.graph) else yt.YOLOLoss()
 opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
 
 def step(timing=None):

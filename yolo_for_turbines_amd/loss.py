@@ -37,3 +37,56 @@ class YOLOLoss(nn.Module):
             class_loss = self.cross_entropy(predictions[..., 5:][has_obj], targets[..., 5][has_obj].long())
         return [self.lambda_box * box_loss, self.lambda_obj * object_loss, self.lambda_noobj * no_obj_loss,
                 self.lambda_class * class_loss]
+
+
+class _FusedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, anchors):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        B, A, g, _, D = pred.shape
+        dev = pred.device
+        with torch.cuda.device(dev):
+            out = torch.empty(4, dtype=torch.float32, device=dev)
+            counts = torch.empty(2, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.yolo_loss_workspace_bytes(B, g), dtype=torch.uint8, device=dev)
+            strides = (C.c_int64 * 5)(*pred.stride())
+            L.check(lib.yolo_loss_fwd(pred.data_ptr(), strides, target.data_ptr(), anchors.data_ptr(), B, g, D - 5, out.data_ptr(),
+                                      counts.data_ptr(), ws.data_ptr(), ws.numel(), L.current_stream()), "yolo_loss_fwd")
+        ctx.save_for_backward(pred, target, anchors, counts)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes as C
+        from . import _lib as L
+        pred, target, anchors, counts = ctx.saved_tensors
+        B, A, g, _, D = pred.shape
+        with torch.cuda.device(pred.device):
+            dpred = torch.empty((B, A, g, g, D), dtype=torch.float32, device=pred.device)
+            gout = gout.float().contiguous()
+            strides = (C.c_int64 * 5)(*pred.stride())
+            L.check(L.lib().yolo_loss_bwd(pred.data_ptr(), strides, target.data_ptr(), anchors.data_ptr(), B, g, D - 5,
+                                          counts.data_ptr(), gout.data_ptr(), dpred.data_ptr(), L.current_stream()), "yolo_loss_bwd")
+        return dpred, None, None
+
+
+class FusedYOLOLoss(nn.Module):
+    """Same values and gradients as :class:`YOLOLoss` (reference `loss.py:29-81`) from three fused HIP
+    kernels per scale instead of ~35 boolean-mask / reduction launches: no data-dependent shapes, no host
+    sync, deterministic sums — so a whole fine-tune step can be captured in a HIP graph
+    (``tools/train_bench.py --graph``). Same call signature and return value; it does NOT mutate
+    ``predictions`` / ``targets`` (the reference overwrites ``predictions[...,1:3]`` and ``targets[...,2:4]``)."""
+
+    def forward(self, predictions, targets, anchors):
+        if not predictions.is_cuda:
+            raise RuntimeError("FusedYOLOLoss runs on MI355X only (no CPU fallback); use YOLOLoss on the CPU")
+        if predictions.dtype != torch.float32 or predictions.dim() != 5 or predictions.shape[1] != 3:
+            raise ValueError("predictions must be an fp32 (B,3,g,g,5+nc) tensor")
+        t = targets.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+        a = anchors.detach().reshape(3, 2).to(device=predictions.device, dtype=torch.float32).contiguous()
+        out = _FusedLossFn.apply(predictions, t, a)
+        return [out[0], out[1], out[2], out[3]]
