@@ -124,6 +124,37 @@ def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
                 kept_mean=float(count.float().mean())), batch
 
 
+def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
+    """cells_to_boxes (utils.py:86-148) for the three scales of one batch: an HBM-bound pass. Algorithmic bytes
+    (SURVEY 8d): B * sum(3 g^2) * ((5+nc)*4 read + 4*4 written back in place + 6*4 boxes written)."""
+    g = [size // 32, size // 16, size // 8]
+    gen = torch.Generator().manual_seed(11)
+    preds = [torch.randn((batch, 3, gg, gg, 5 + nc), generator=gen).to(device) for gg in g]
+    anchors = [torch.rand((3, 2), generator=gen).to(device) * gg for gg in g]
+    n_total = sum(3 * gg * gg for gg in g)
+    out = torch.empty((batch, n_total, 6), dtype=torch.float32, device=device)
+
+    def run():
+        off = 0
+        for p, a, gg in zip(preds, anchors, g):
+            yt.decode_boxes(p, a, gg, True, out=out, box_offset=off)
+            off += 3 * gg * gg
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = batch * n_total * ((5 + nc) * 4 + 4 * 4 + 6 * 4)
+    return {"workload": f"batch {batch}, {size}x{size}, {nc} classes: {n_total} boxes/image, 3 launches", "ms": round(ms, 4),
+            "boxes_per_s": round(batch * n_total / ms * 1e3, 1), "algorithmic_bytes": nbytes,
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(nbytes / ms / 1e6 / 8000.0, 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,7 +357,8 @@ def main():
         nms_batch = None
         if not args.no_nms:
             result["nms"], nms_batch = nms_bench(yt, device)
-            log("nms bench done")
+            result["decode"] = decode_bench(yt, device)
+            log("nms + decode bench done")
         # -------------------------------------------------------------------------- CPU baseline
         if world == 1 and not args.no_cpu_baseline:
             from oracle import net as onet

@@ -196,7 +196,6 @@ __global__ __launch_bounds__(256) void wgrad_patch_h16(const WgradHArgs p) {
             }
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                constexpr int dummy = 0; (void)dummy;
                 const int dh = tap / KS, dw = tap % KS;
 #pragma unroll
                 for (int j = 0; j < TT; ++j) {

@@ -483,20 +483,19 @@ def _run_module_plan(module, x, prog, cur, out, stream, dt="fp32"):
     lib = L.lib()
     B, Cc, H, W = x.shape
     cpad = cur.ld
-    if True:
-        plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override, dtype=dt)
-        _module_state.refresh_weights(plan.blocks, x.device, stream, dt)
-        xin = x.detach().float().contiguous()
-        plan.load_input(xin, stream)
-        result = None
-        if out is None:
-            i, g, c3 = plan.pred_ops[0]
-            result = torch.empty((B, 3, g, g, c3), dtype=torch.float32, device=x.device)
-            plan.table[i].y = result.data_ptr()
-        plan.launch(stream)
-        if out is not None:
-            result = torch.empty((B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
-            L.check(lib.yolo_nhwc_to_nchw(plan.phys[out.buf].data_ptr(), result.data_ptr(), B, out.C, out.H, out.W,
-                                          out.ld, out.off, plan.code, stream), "yolo_nhwc_to_nchw")
-        torch.cuda.current_stream().synchronize()      # plan buffers die with this call
+    plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override, dtype=dt)
+    _module_state.refresh_weights(plan.blocks, x.device, stream, dt)
+    xin = x.detach().float().contiguous()
+    plan.load_input(xin, stream)
+    result = None
+    if out is None:
+        i, g, c3 = plan.pred_ops[0]
+        result = torch.empty((B, 3, g, g, c3), dtype=torch.float32, device=x.device)
+        plan.table[i].y = result.data_ptr()
+    plan.launch(stream)
+    if out is not None:
+        result = torch.empty((B, out.C, out.H, out.W), dtype=torch.float32, device=x.device)
+        L.check(lib.yolo_nhwc_to_nchw(plan.phys[out.buf].data_ptr(), result.data_ptr(), B, out.C, out.H, out.W,
+                                      out.ld, out.off, plan.code, stream), "yolo_nhwc_to_nchw")
+    torch.cuda.current_stream().synchronize()      # plan buffers die with this call
     return result
