@@ -48,7 +48,18 @@ struct ConvHArgs {
     int Ho, Wo;
     int first_wave, stagger;
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
+    // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
+    // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
+    unsigned mg_H, mg_TW, mg_PC, mg_tn, mg_tw;
 };
+
+// x / d for 0 <= x < 2^31 with mg = ceil(2^32 / d) (d >= 2) or 0 (d == 1): the estimate is q or q + 1, one fix-up
+__device__ __forceinline__ int fdiv(int x, unsigned mg, int d) {
+    if (!mg) return x;
+    const int q = (int)__umulhi((unsigned)x, mg);
+    return (long long)q * d > x ? q - 1 : q;
+}
+static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
 template <typename T> struct HTraits;
 template <> struct HTraits<__bf16> {
@@ -114,6 +125,9 @@ __device__ __forceinline__ void h_kstep(const ConvHArgs& p, const HCtx<T, TN>& c
 #pragma unroll
             for (int s = 0; s < 2; ++s) an[i][s] = *reinterpret_cast<const u32x4*>(Ab_next + c.a_off[i] + s * 32);
     }
+    // keep the next step's A reads HERE, ahead of this step's 8 MFMAs: left free, the scheduler sinks them to just
+    // before their first use and every K step starts with an exposed LDS round trip (seen in the ISA)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -198,6 +212,9 @@ __device__ __forceinline__ void h_kstep_m(const ConvHArgs& p, const HCtx<T, TN>&
 #pragma unroll
             for (int s = 0; s < 2; ++s) an[i][s] = *reinterpret_cast<const u32x4*>(Ab_next + c.a_off[i] + s * 32);
     }
+    // keep the next step's A reads HERE, ahead of this step's 8 MFMAs: left free, the scheduler sinks them to just
+    // before their first use and every K step starts with an exposed LDS round trip (seen in the ISA)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -305,23 +322,27 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
         const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
-    const int n_tile = bid % p.tiles_n;
-    const int sp = bid / p.tiles_n;
-    const int w_tile = sp % p.tiles_w;
-    const int r_tile = sp / p.tiles_w;
+    const int sp = fdiv(bid, p.mg_tn, p.tiles_n);
+    const int n_tile = bid - sp * p.tiles_n;
+    const int r_tile = fdiv(sp, p.mg_tw, p.tiles_w);
+    const int w_tile = sp - r_tile * p.tiles_w;
     const int g0 = r_tile * p.TH, c0 = w_tile * p.TW;
     const int g_last = (g0 + p.TH < p.rows_total ? g0 + p.TH : p.rows_total) - 1;
     const int Hp = p.Hin + 2;
-    auto vrow = [&](int g) { return KS == 3 ? (g / p.H) * Hp + STRIDE * (g % p.H) : g; };
+    auto vrow = [&](int g) {
+        if (KS != 3) return g;
+        const int n = fdiv(g, p.mg_H, p.H);
+        return n * Hp + STRIDE * (g - n * p.H);
+    };
     const int v0 = vrow(g0);
     const int PR = vrow(g_last) + (KS == 3 ? 3 : 1) - v0;
 
     HCtx<T, TN> c;
     c.KT = p.KT;
     {   // staged patch pixels of this 4-lane group: idx = (tid >> 2) + 64 i
-        const int d_pr = 64 / p.PC, d_pc = 64 - d_pr * p.PC;
-        int pr = (tid >> 2) / p.PC, pc = (tid >> 2) - pr * p.PC;
-        const int n0i = KS == 3 ? v0 / Hp : 0;
+        const int d_pr = fdiv(64, p.mg_PC, p.PC), d_pc = 64 - d_pr * p.PC;
+        int pr = fdiv(tid >> 2, p.mg_PC, p.PC), pc = (tid >> 2) - pr * p.PC;
+        const int n0i = KS == 3 ? fdiv(g0, p.mg_H, p.H) : 0;            // image of the tile's first row (v0 / Hp)
 #pragma unroll
         for (int i = 0; i < H_NI; ++i) {
             int pix = -1;
@@ -344,19 +365,19 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pp = wm * 64 + i * 32 + frow;
-        const int r = pp / p.TW, cc = pp - r * p.TW;
+        const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
         const int g = g0 + r;
         const bool ok = pp < p.TH * p.TW && g <= g_last && c0 + cc < p.W;
         c.a_off[i] = (ok ? ((vrow(g) - v0) * p.PC + STRIDE * cc) * H_PIX_BYTES : 0) + 16 * fh;
         if (MASK) c.a_off[i] += ((mask_nth(MASK, 0) / 3) * p.PC + mask_nth(MASK, 0) % 3) * H_PIX_BYTES;
     }
     if (tid < 128) {
-        const int r = tid / p.TW, cc = tid - r * p.TW;
+        const int r = fdiv(tid, p.mg_TW, p.TW), cc = tid - r * p.TW;
         const int g = g0 + r;
         int m = -1;
         if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
             if (MASK) {                               // parity class: dx pixel (2r + ph, 2c + pw) of image n
-                const int n = g / p.H, rr = g - n * p.H;
+                const int n = fdiv(g, p.mg_H, p.H), rr = g - n * p.H;
                 m = (n * 2 * p.H + 2 * rr + p.cls_ph) * (2 * p.W) + 2 * (c0 + cc) + p.cls_pw;
             } else {
                 m = g * p.W + c0 + cc;
@@ -662,6 +683,11 @@ int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtyp
     return YOLO_OK;
 }
 
+static void fill_magics(ConvHArgs& a) {
+    a.mg_H = magic_of(a.H); a.mg_TW = magic_of(a.TW); a.mg_PC = magic_of(a.PC);
+    a.mg_tn = magic_of(a.tiles_n); a.mg_tw = magic_of(a.tiles_w);
+}
+
 static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax) {
     if (ks == 1) { *th = 1; *tw = 128; *prmax = 1; return; }
     double best = -1;
@@ -687,6 +713,7 @@ static int launch_h(ConvHArgs& a, hipStream_t s) {
     a.tiles_n = ceil_div(a.Cout, BN);
     const int tiles_r = ceil_div(a.rows_total, a.TH);
     a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
+    fill_magics(a);
     a.first_wave = 2 * 256;
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;      // one block's matrix cycles per wave
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;   // s_sleep 32 = 2048 cycles
@@ -700,6 +727,7 @@ static int launch_cls(ConvHArgs& a, hipStream_t s) {
     a.tiles_n = ceil_div(a.Cout, BN);
     const int tiles_r = ceil_div(a.rows_total, a.TH);
     a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
+    fill_magics(a);
     a.first_wave = 2 * 256;
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
