@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-block phase stamps of conv_patch_h16 (diagnostic build with -DH16_STAMPS, loaded through YOLO_MI355X_LIB).
+"""Per-block phase stamps of conv_patch_h16 (diagnostic build: `make -C yolo_for_turbines_amd/csrc stamps`, then YOLO_MI355X_LIB=yolo_for_turbines_amd/libyolo_mi355x_stamps.so).
 Prints phase lengths (prologue / main loop / epilogue), per-CU concurrency and the gap between consecutive blocks
 of one workgroup slot."""
 import os, sys

@@ -310,6 +310,9 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fh = lane >> 5, frow = lane & 31;
+#ifdef H16_STAMPS   // diagnostic build (make stamps): per-block phase stamps into the buffer passed as nan_flag
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
 
     if (p.stagger > 0 && (int)blockIdx.x < p.first_wave) {             // see conv_f32_v2.hip
         unsigned hw;
@@ -430,6 +433,10 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(patch + c.a_off[i] + s * 32);
 
+#ifdef H16_STAMPS
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (MASK != 0) {
         int chunk = 0;
         for (; chunk + 3 <= p.nchunks; chunk += 3) {
@@ -452,6 +459,10 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
         if (chunk + 1 < p.nchunks) h_kstep_1x1<T, TN, 1>(p, c, chunk + 1, patch, ring, stage, af, acc, tid);
     }
 
+#ifdef H16_STAMPS
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---------------------------------------------------------------------- epilogue (fp32 math)
     const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
@@ -548,6 +559,19 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
         if (j + 1 < TN) __syncthreads();
     }
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+#ifdef H16_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.nan_flag) + (size_t)blockIdx.x * 6;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = hw; o[5] = xcc;
+        }
+    }
+#endif
 }
 
 // fragment-order 16-bit weights: [n_tile32][kt][s(2)][lane(64)][e(8)], n = nt*32 + (lane&31),
