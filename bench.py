@@ -169,8 +169,11 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="compute dtype of the forward leg (BASELINE configs[1] = fp32; fp16 / bf16 = configs 4-5 arithmetic)")
-    ap.add_argument("--config5", action="store_true",
-                    help="also time BASELINE config 5 per-GPU shape: batch 16, 608x608 fp16 forward + decode + per-image NMS")
+    ap.add_argument("--config5", action="store_true", help="(default on; kept for compatibility)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip BASELINE config 5 per-GPU shape: batch 16, 608x608 fp16 forward + decode + per-image NMS")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip BASELINE config 3 shape: batch 64 multi-scale fine-tune steps (S cycles through 320..608)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
     ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
     args = ap.parse_args()
@@ -279,12 +282,40 @@ def main():
         # BASELINE configs[3] arithmetic: the same step under torch.autocast(bf16) (train.py:53) -> 16-bit kernels for
         # activations and activation gradients, fp32 master weights / statistics / parameter gradients
         train["bf16_autocast"] = train_leg(torch.bfloat16)
+        # ---- BASELINE configs[2] shape: batch 64, 2 classes, S switching between sizes (train.py:45-46; the list
+        # there is 416..608, SURVEY 8d widens it to 320..608). 2 timed steps per size after 1 untimed at the new size
+        # (plan build + first-touch of ~60 GB of buffers is a per-switch cost the reference pays every 10 batches).
+        if not args.no_config3 and world == 1:
+            sizes, b3 = [320, 416, 512, 608], 64
+            per_size, tot_img, tot_t = {}, 0, 0.0
+            lf3 = yt.FusedYOLOLoss()
+            for S3 in sizes:
+                x3 = torch.rand((b3, 3, S3, S3), generator=g).to(device)
+                g3 = [S3 // 32, S3 // 16, S3 // 8]
+                sa3 = (torch.tensor(anchors) * torch.tensor(g3).view(3, 1, 1)).to(device)
+                tg3 = [torch.from_numpy(t).to(device) for t in gi.synth_targets(b3, S3, args.train_classes, anchors, 7)]
+
+                def step3():
+                    opt.zero_grad(set_to_none=True)
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        preds = tm(x3)
+                    loss = sum(sum(lf3(preds[i], tg3[i], sa3[i])) for i in range(3))
+                    loss.backward()
+                    opt.step()
+                t3_el = ydist.timed_steps(step3, 2, 1, dist, device)
+                per_size[str(S3)] = round(b3 * 2 / t3_el, 1)
+                tot_img += b3 * 2
+                tot_t += t3_el
+                del x3, tg3
+            train["config3_multiscale"] = {"workload": "batch 64, 2 classes, bf16 autocast, S in [320,416,512,608], 2 steps per size",
+                                           "value": round(tot_img / tot_t, 2), "unit": "images/s", "images_per_s_by_size": per_size}
+            log(f"config3 leg: {tot_img / tot_t:.1f} img/s")
         del tm, opt
         torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- config 5 leg (optional)
     cfg5 = None
-    if args.config5:
+    if not args.no_config5:
         m5 = seeded_model(yt, 80, device, seed=2)
         m5._engine.compute_dtype = "fp16"
         x5 = torch.rand((16, 3, 608, 608), generator=g).to(device)

@@ -699,3 +699,38 @@ def test_fused_loss_reference_view_and_empty_object_set(yt):
         ref = torch.stack([torch.as_tensor(v) for v in oloss.yolo_loss(view_cpu.clone(), tt.clone(), anc)])
         got = torch.stack(fl(raw.cuda().permute(0, 1, 3, 4, 2), tt.cuda(), anc.cuda()))
         np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_plan_cache_is_bounded_across_sizes(yt):
+    """Multi-scale training (train.py:45-46) visits many input sizes; each training plan owns all activations of its
+    size, so the engine keeps only the most recently used ones (and rebuilding a dropped plan gives the same result)."""
+    nc = 2
+    sd = onet.synth_state_dict(61, 3, nc, gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=nc)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    lf = yt.FusedYOLOLoss()
+    anchors = gi.TRAIN_CASE["anchors"]
+    first = None
+    for S in (64, 96, 128, 160, 64):
+        x = onet.synth_input(S, 2, S).cuda()
+        tg = [torch.from_numpy(t).cuda() for t in gi.synth_targets(2, S, nc, anchors, 5)]
+        sa = (torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)).cuda()
+        m.zero_grad(set_to_none=True)
+        preds = m(x)
+        loss = sum(sum(lf(preds[i], tg[i], sa[i])) for i in range(3))
+        loss.backward()
+        if S == 64:
+            gnorm = float(m.layers[0].conv.weight.grad.double().norm())
+            if first is None:
+                first = (float(loss), gnorm)
+            else:
+                assert abs(float(loss) - first[0]) <= 1e-4 * abs(first[0]) + 1e-5     # running stats moved; forward uses batch stats
+                assert abs(gnorm - first[1]) <= 1e-3 * first[1]
+        n_train = sum(1 for k in m._engine._plans if k[0] == "train")
+        assert n_train <= m._engine.max_train_plans
+    m.eval()
+    with torch.no_grad():
+        for S in (32, 64, 96, 128, 160, 192):
+            m(onet.synth_input(S, 1, S).cuda())
+    assert sum(1 for k in m._engine._plans if k[0] == "eval") <= m._engine.max_eval_plans

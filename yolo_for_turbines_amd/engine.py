@@ -357,6 +357,22 @@ class ModelState:
         self.tile_override = None
         self.compute_dtype = None        # None: follow torch.autocast (fp32 outside it); or "fp32" / "fp16" / "bf16"
         self.ddp = None                  # (torch.distributed module, bucket MB) when data-parallel (dist.data_parallel)
+        # Plans own their activation buffers (a batch-64 608x608 training plan is ~60 GB): keep the most recently
+        # used few, so multi-scale training (train.py:45-46 switches S every 10 batches) does not accumulate one
+        # full set of buffers per size.
+        self.max_train_plans = 2
+        self.max_eval_plans = 4
+
+    def _remember(self, key, plan):
+        """Insert / refresh ``plan`` as most recently used and evict the oldest plans of its kind beyond the cap."""
+        self._plans.pop(key, None)
+        self._plans[key] = plan
+        is_train = key[0] == "train"
+        cap = self.max_train_plans if is_train else self.max_eval_plans
+        same = [k for k in self._plans if (k[0] == "train") == is_train]
+        for k in same[:max(0, len(same) - cap)]:
+            del self._plans[k]
+        return plan
 
     def __getstate__(self):
         return {"nan_check": self.nan_check}
@@ -413,13 +429,14 @@ class ModelState:
         with torch.cuda.device(x.device):
             stream = L.current_stream()
             dt = resolve_dtype(self.compute_dtype)
-            key = (B, H, x.device.index, self.tile_override, dt)
+            key = ("eval", B, H, x.device.index, self.tile_override, dt)
             plan = self._plans.get(key)
             if plan is None:
                 prog = build_network_program(model, B, H, ch_align=8 if dt != "fp32" else 4)
-                plan = self._plans[key] = Plan(prog, self, x.device, self.tile_override, dtype=dt)
+                plan = Plan(prog, self, x.device, self.tile_override, dtype=dt)
                 if dt != "fp32" and plan.stem is None:
                     raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
+            self._remember(key, plan)
             self.refresh_weights(plan.blocks, x.device, stream, dt)
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():

@@ -376,9 +376,10 @@ def forward_train(state, model, x):
         plan = state._plans.get(key)
         if plan is None:
             prog = build_network_program(model, B, H)
-            plan = state._plans[key] = TrainPlan(prog, x.device, dt)
+            plan = TrainPlan(prog, x.device, dt)
             if dt != "fp32" and not plan.stem:
                 raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
+        state._remember(key, plan)
         plist = [p for p in model.parameters()]
         holder = (state, model, plan, plist)
         preds = YoloTrainFn.apply(x, holder, *plist)
