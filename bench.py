@@ -155,6 +155,23 @@ def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
                          "frac": round(nbytes / ms / 1e6 / 8000.0, 4)}}
 
 
+COCO_ANCHORS = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+                [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
+
+
+def gi_boxes(batch, mean_boxes=9, seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    anc = np.asarray(COCO_ANCHORS).reshape(9, 2)
+    out = []
+    for _ in range(batch):
+        n = max(1, rng.poisson(mean_boxes))
+        a = rng.integers(0, 9, n)
+        wh = np.clip(anc[a] * np.exp(0.3 * rng.standard_normal((n, 2))), 0.01, 0.95)
+        xy = rng.uniform(0.01, 0.99, (n, 2))
+        out.append(np.concatenate([xy, wh, rng.integers(0, 80, (n, 1))], 1).astype(np.float32).tolist())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,7 +406,18 @@ def main():
         if not args.no_nms:
             result["nms"], nms_batch = nms_bench(yt, device)
             result["decode"] = decode_bench(yt, device)
-            log("nms + decode bench done")
+            # ground-truth tensor builder (dataset.py:119-161) for one batch-64 416x416 batch of seeded COCO-shaped boxes
+            tb = gi_boxes(64)
+            yt.build_targets(tb, COCO_ANCHORS, 416)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                yt.build_targets(tb, COCO_ANCHORS, 416)
+            torch.cuda.synchronize()
+            dt_t = (time.perf_counter() - t0) / 10
+            result["targets"] = {"workload": "batch 64, 416x416, ~9 boxes/image incl. host list -> device copy", "ms": round(dt_t * 1e3, 3),
+                                 "images_per_s": round(64 / dt_t, 1)}
+            log("nms + decode + targets bench done")
         # -------------------------------------------------------------------------- CPU baseline
         if world == 1 and not args.no_cpu_baseline:
             from oracle import net as onet

@@ -170,6 +170,14 @@ int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_pack
 /* upstream gradient in the head layout (B,3,g,g,D) fp32, any strides -> NHWC (B,g,g,ld) in dtype, channel a*D+k, pads 0 */
 int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream);
 
+/* ---- ground-truth tensors (next to the hot path: dataset.py:119-161) ------------------------ */
+/* boxes (B, max_boxes, 5) fp32 [x, y, w, h, class] normalised to [0,1), counts (B) valid boxes per image (list order
+ * matters), anchors (9,2) normalised and scale-major (config.ANCHORS flattened). Writes the three target tensors
+ * (B,3,g,g,6), g = S/32, S/16, S/8, rows [x_cell, y_cell, w_cells, h_cells, obj in {1,0,-1}, class] — zero-filled
+ * here first. Same assignment rule and quirks as the reference loop (see csrc/targets.hip). */
+int yolo_build_targets(const float* boxes, const int32_t* counts, int max_boxes, const float* anchors_9x2, int b, int image_size,
+                       float ignore_iou, float* t0, float* t1, float* t2, void* stream);
+
 /* ---- fused per-scale loss (optional replacement of YOLOLoss.forward, loss.py:29-81) -------- */
 /* pred (B,3,g,g,5+nc) fp32 through element strides; target (B,3,g,g,6) fp32 contiguous
  * [x_cell,y_cell,w_cells,h_cells,obj in {1,0,-1},class]; anchors (3,2) in grid units.

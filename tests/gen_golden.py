@@ -300,8 +300,33 @@ def gen_kat():
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
 
 
+def gen_targets():
+    """Targets from the reference's OWN YOLODataset.__getitem__ (dataset.py:119-161): the dataset object is built on
+    a one-line csv + an empty label file in a temp dir, and only its I/O hooks (image / label loading, augmentation)
+    are replaced so that the seeded box list reaches the assignment loop unchanged."""
+    import tempfile
+    import dataset as ref_dataset
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "split.csv"), "w") as f:
+            f.write("img.jpg,label.txt\nimg2.jpg,missing.txt\n")
+        open(os.path.join(tmp, "label.txt"), "w").close()
+        for name, c in gi.TARGET_CASES.items():
+            S = c["size"]
+            ds = ref_dataset.YOLODataset(os.path.join(tmp, "split.csv"), tmp, tmp, [list(map(list, a)) for a in c["anchors"]], batch_size=1,
+                                         image_size=S, grid_sizes=[S // 32, S // 16, S // 8], num_classes=c["nc"])
+            ds.load_image = lambda idx: np.zeros((S, S, 3), np.uint8)
+            for b, boxes in enumerate(gi.target_boxes(name)):
+                ds.load_boxes = lambda label_path, idx, _b=boxes: [list(r) for r in _b]
+                ds.apply_augmentations = lambda img, bx, idx: (img, bx)
+                _, t = ds[0]
+                for s_i, tt in enumerate(t):
+                    out[f"{name}/img{b}/scale{s_i}"] = tt.numpy()
+    np.savez_compressed(os.path.join(OUT, "targets.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat"]
+    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat", "targets"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

@@ -211,3 +211,37 @@ def synth_targets(batch, size, nc, anchors, seed, mean_boxes=7):
                 elif not taken and iou[ai] > 0.5:
                     out[s][b, k, i, j, 4] = -1.0
     return out
+
+
+# -------------------------------------------------------------------- target-builder cases (dataset.py:119-161)
+COCO_ANCHORS = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+                [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]                       # config.ANCHORS
+TARGET_CASES = {
+    "s416_coco": dict(size=416, nc=80, batch=6, seed=401, anchors=COCO_ANCHORS, mean_boxes=9),
+    "s320_turbine": dict(size=320, nc=2, batch=5, seed=402, anchors=TRAIN_CASE["anchors"], mean_boxes=4),
+    "s608_crowded": dict(size=608, nc=80, batch=3, seed=403, anchors=COCO_ANCHORS, mean_boxes=60),
+    "s96_collisions": dict(size=96, nc=3, batch=4, seed=404, anchors=COCO_ANCHORS, mean_boxes=25),
+}
+
+
+def target_boxes(case):
+    """Seeded per-image box lists [[x, y, w, h, class], ...] with fp32-representable coordinates (the reference
+    gets Python floats, the kernel fp32: identical values). Image 0 has no boxes; the last image carries boxes on exact
+    cell corners (x offset 0: the reference's "taken" test, dataset.py:141, then sees a free cell) and duplicates."""
+    c = TARGET_CASES[case]
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    anc = np.asarray(c["anchors"], np.float64).reshape(9, 2)
+    out = []
+    for b in range(c["batch"]):
+        n = 0 if b == 0 else max(1, rng.poisson(c["mean_boxes"]))
+        boxes = []
+        for _ in range(n):
+            a = rng.integers(0, 9)
+            w, h = np.clip(anc[a] * np.exp(0.3 * rng.standard_normal(2)), 0.01, 0.95)
+            x, y = rng.uniform(0.01, 0.99, 2)
+            boxes.append([float(F32(x)), float(F32(y)), float(F32(w)), float(F32(h)), float(rng.integers(0, c["nc"]))])
+        if b == c["batch"] - 1:
+            extra = [[0.5, 0.5, 0.2, 0.3, 1.0], [0.5, 0.5, 0.21, 0.29, 0.0], [0.25, 0.75, 0.05, 0.06, 1.0], [0.25, 0.75, 0.05, 0.06, 1.0]]
+            boxes += [[float(F32(v)) for v in r] for r in extra]
+        out.append(boxes)
+    return out

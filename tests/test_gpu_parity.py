@@ -734,3 +734,29 @@ def test_plan_cache_is_bounded_across_sizes(yt):
         for S in (32, 64, 96, 128, 160, 192):
             m(onet.synth_input(S, 1, S).cuda())
     assert sum(1 for k in m._engine._plans if k[0] == "eval") <= m._engine.max_eval_plans
+
+
+# ------------------------------------------------------------- batched target builder (dataset.py:119-161)
+@pytest.mark.parametrize("case", list(gi.TARGET_CASES))
+def test_build_targets_bit_exact_vs_reference(yt, golden, case):
+    """yolo_build_targets for a whole batch against what the reference's YOLODataset.__getitem__ built per image
+    (goldens generated by running that code): every element identical, including the empty image, overwritten
+    'free-looking' cells (x offset 0) and the ignore (-1) marks."""
+    g = golden("targets")
+    c = gi.TARGET_CASES[case]
+    boxes = gi.target_boxes(case)
+    outs = yt.build_targets(boxes, c["anchors"], c["size"])
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    for s_i, (o, gg) in enumerate(zip(outs, grids)):
+        assert tuple(o.shape) == (len(boxes), 3, gg, gg, 6) and o.dtype == torch.float32
+        want = np.stack([g[f"{case}/img{b}/scale{s_i}"] for b in range(len(boxes))])
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+    # padded-tensor entry point gives the same tensors
+    mb = max(len(b) for b in boxes)
+    pad = torch.zeros((len(boxes), mb + 3, 5))
+    for i, bl in enumerate(boxes):
+        if bl:
+            pad[i, :len(bl)] = torch.tensor(bl)
+    outs2 = yt.build_targets(pad.cuda(), c["anchors"], c["size"], counts=[len(b) for b in boxes])
+    for a, b2 in zip(outs, outs2):
+        assert torch.equal(a, b2)

@@ -200,3 +200,19 @@ def test_train_step_losses_and_grads(golden):
         scale = max(1e-6, float(np.abs(want).max()))
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-3 * scale)
     np.testing.assert_allclose(stats["layers.0.batch_norm.running_mean"].numpy(), g["leaky/rm0"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ target builder (dataset.py:119-161)
+@pytest.mark.parametrize("case", list(gi.TARGET_CASES))
+def test_targets_oracle_equals_reference_getitem(golden, case):
+    """oracle/targets.py against the tensors the reference's own YOLODataset.__getitem__ produced for the same
+    seeded box lists (empty image, crowded cells, boxes on exact cell corners, duplicates)."""
+    from oracle import targets as otg
+    g = golden("targets")
+    c = gi.TARGET_CASES[case]
+    for b, boxes in enumerate(gi.target_boxes(case)):
+        got = otg.build_targets_image(boxes, c["anchors"], c["size"])
+        for s_i in range(3):
+            want = g[f"{case}/img{b}/scale{s_i}"]
+            assert got[s_i].shape == want.shape
+            np.testing.assert_array_equal(got[s_i].numpy(), want)

@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
-           "detect"]
+           "detect", "build_targets"]
 
 
 # -------------------------------------------------------------------------------- IoU
@@ -148,3 +148,41 @@ def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, b
         off += n
     keep, count = nms_indices(boxes, iou_threshold, obj_threshold, box_format)
     return boxes, keep, count
+
+
+# ------------------------------------------------------------------------------ targets
+def build_targets(boxes, anchors, image_size, counts=None, ignore_iou_threshold=0.5, device=None):
+    """Batched device version of the target loop of ``YOLODataset.__getitem__`` (dataset.py:119-161).
+
+    ``boxes``: per-image lists ``[[x, y, w, h, class], ...]`` (normalised, the dataset's order) or a padded
+    ``(B, max_boxes, 5)`` tensor with ``counts`` (B). ``anchors``: the 3x3x2 normalised anchor table
+    (``config.ANCHORS``). Returns the tuple of three ``(B, 3, g, g, 6)`` fp32 tensors the loss consumes."""
+    if isinstance(boxes, torch.Tensor):
+        if counts is None:
+            raise ValueError("a padded box tensor needs `counts`")
+        bt = boxes.to(dtype=torch.float32)
+        dev = bt.device if device is None else torch.device(device)
+        ct = torch.as_tensor(counts, dtype=torch.int32)
+    else:
+        B = len(boxes)
+        mb = max(1, max((len(b) for b in boxes), default=1))
+        host = torch.zeros((B, mb, 5), dtype=torch.float32)
+        ct = torch.tensor([len(b) for b in boxes], dtype=torch.int32)
+        for i, bl in enumerate(boxes):
+            if len(bl):
+                host[i, :len(bl)] = torch.as_tensor(bl, dtype=torch.float32).reshape(-1, 5)
+        bt = host
+        dev = torch.device("cuda" if device is None else device)
+    if dev.type != "cuda":
+        raise RuntimeError("build_targets runs on MI355X only (no CPU fallback)")
+    bt = bt.to(dev).contiguous()
+    ct = ct.to(dev).contiguous()
+    anc = torch.as_tensor(anchors, dtype=torch.float32).reshape(9, 2).to(dev).contiguous()
+    B, mb = bt.shape[0], bt.shape[1]
+    S = int(image_size)
+    with torch.cuda.device(dev):
+        outs = [torch.empty((B, 3, g, g, 6), dtype=torch.float32, device=dev) for g in (S // 32, S // 16, S // 8)]
+        L.check(L.lib().yolo_build_targets(bt.data_ptr(), ct.data_ptr(), mb, anc.data_ptr(), B, S, float(ignore_iou_threshold),
+                                           outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), L.current_stream()),
+                "yolo_build_targets")
+    return tuple(outs)
