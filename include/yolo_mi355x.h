@@ -178,6 +178,15 @@ int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, 
 int yolo_build_targets(const float* boxes, const int32_t* counts, int max_boxes, const float* anchors_9x2, int b, int image_size,
                        float ignore_iou, float* t0, float* t1, float* t2, void* stream);
 
+/* ---- evaluation: average precision per class (utils.py:193-274) ----------------------------- */
+/* rows are [image, x, y, w, h, objectness, class] fp32. dets_sorted: class ascending, objectness descending (stable);
+ * gts_sorted: class ascending, image ascending (stable); *_class_offsets: [num_classes + 1] row ranges.
+ * assigned: n_gt int32 scratch, tp_flags: one fp32 per detection (1 = true positive), ap_per_class: trapezoid area of the
+ * precision/recall curve, -1 for classes without ground truth (the reference skips them). */
+int yolo_map_match(const float* dets_sorted, const int32_t* det_class_offsets, const float* gts_sorted, const int32_t* gt_class_offsets,
+                   int num_classes, int n_gt, float iou_threshold, int center, int32_t* assigned, float* tp_flags, float* ap_per_class,
+                   void* stream);
+
 /* ---- fused per-scale loss (optional replacement of YOLOLoss.forward, loss.py:29-81) -------- */
 /* pred (B,3,g,g,5+nc) fp32 through element strides; target (B,3,g,g,6) fp32 contiguous
  * [x_cell,y_cell,w_cells,h_cells,obj in {1,0,-1},class]; anchors (3,2) in grid units.

@@ -297,6 +297,10 @@ def gen_kat():
     out["iou_center"] = ref_utils.calc_iou(torch.from_numpy(a), torch.from_numpy(c), "center").numpy()
     out["iou_corners"] = ref_utils.calc_iou(torch.from_numpy(a), torch.from_numpy(c), "corners").numpy()
     out["iou_aligned"] = ref_utils.iou_aligned(torch.from_numpy(a[:, 2:]), torch.from_numpy(c[:, 2:])).numpy()
+    for name, c in gi.MAP_CASES.items():                           # calc_mAP of the reference itself on seeded box lists
+        pb, tb = gi.map_boxes(name)
+        out[f"map_{name}"] = np.array(float(ref_utils.calc_mAP([r[:] for r in pb], [r[:] for r in tb], 0.5, "center", c["nc"])))
+        out[f"map_{name}_iou75"] = np.array(float(ref_utils.calc_mAP([r[:] for r in pb], [r[:] for r in tb], 0.75, "center", c["nc"])))
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
 
 

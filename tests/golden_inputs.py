@@ -245,3 +245,43 @@ def target_boxes(case):
             boxes += [[float(F32(v)) for v in r] for r in extra]
         out.append(boxes)
     return out
+
+
+# -------------------------------------------------------------------- mAP cases (utils.py:193-274)
+MAP_CASES = {
+    "small": dict(images=4, nc=3, gt_mean=3, seed=501, dup=1, noise=4),
+    "coco_like": dict(images=12, nc=20, gt_mean=6, seed=502, dup=2, noise=10),
+    "two_class_dense": dict(images=6, nc=2, gt_mean=20, seed=503, dup=3, noise=30),
+    "ties": dict(images=3, nc=2, gt_mean=4, seed=504, dup=2, noise=3, quantise=True),
+}
+
+
+def map_boxes(case):
+    """Seeded (pred_boxes, true_boxes) row lists [img, cx, cy, w, h, obj, cls] with fp32-representable values:
+    jittered copies of every ground truth (some above, some below IoU 0.5), duplicates, pure-noise detections,
+    a class with ground truth but no detection and detections of a class without ground truth; `quantise` makes
+    objectness ties (stable sort order matters)."""
+    c = MAP_CASES[case]
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    f = lambda v: float(F32(v))
+    preds, trues = [], []
+    for img in range(c["images"]):
+        n = max(1, rng.poisson(c["gt_mean"]))
+        for _ in range(n):
+            cls = int(rng.integers(0, c["nc"] - 1))                       # the last class never has ground truth
+            cx, cy = rng.uniform(0.15, 0.85, 2)
+            w, h = rng.uniform(0.05, 0.3, 2)
+            trues.append([img, f(cx), f(cy), f(w), f(h), 1.0, cls])
+            if cls == 0 and img == 0:
+                continue                                                  # ground truth that nobody detects
+            for _ in range(c["dup"]):
+                jit = rng.choice([0.02, 0.08, 0.3])
+                s = rng.uniform(0.3, 1.0)
+                if c.get("quantise"):
+                    s = round(s * 5) / 5
+                preds.append([img, f(cx + jit * w * rng.standard_normal()), f(cy + jit * h * rng.standard_normal()),
+                              f(w * np.exp(jit * rng.standard_normal())), f(h * np.exp(jit * rng.standard_normal())), f(s), cls])
+        for _ in range(c["noise"]):
+            preds.append([img, f(rng.uniform(0.1, 0.9)), f(rng.uniform(0.1, 0.9)), f(rng.uniform(0.05, 0.4)), f(rng.uniform(0.05, 0.4)),
+                          f(rng.uniform(0.1, 0.9)), int(rng.integers(0, c["nc"]))])
+    return preds, trues

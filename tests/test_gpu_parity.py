@@ -760,3 +760,36 @@ def test_build_targets_bit_exact_vs_reference(yt, golden, case):
     outs2 = yt.build_targets(pad.cuda(), c["anchors"], c["size"], counts=[len(b) for b in boxes])
     for a, b2 in zip(outs, outs2):
         assert torch.equal(a, b2)
+
+
+# ------------------------------------------------------------- mAP on the device (utils.py:193-274)
+@pytest.mark.parametrize("case", list(gi.MAP_CASES))
+def test_map_vs_reference(yt, golden, case):
+    """calc_mAP (two stable sorts + matching and AP kernels) against the value the reference's own calc_mAP returned
+    for the same seeded detections / ground truths, at IoU 0.5 and 0.75; plus the reference's known-answer test."""
+    g = golden("kat")
+    pb, tb = gi.map_boxes(case)
+    nc = gi.MAP_CASES[case]["nc"]
+    for thr, key in ((0.5, f"map_{case}"), (0.75, f"map_{case}_iou75")):
+        got = yt.calc_mAP(pb, tb, thr, "center", nc)
+        assert got.dim() == 0 and got.dtype == torch.float32
+        assert abs(float(got) - float(g[key])) <= 2e-6, f"{case} @{thr}: {float(got)} vs {float(g[key])}"
+
+
+def test_map_known_answers(yt, golden):
+    pb = [[0, 0.5, 0.5, 0.25, 0.25, 0.9, 0], [0, 0.5, 0.5, 0.1, 0.1, 0.6, 0]]
+    assert abs(float(yt.calc_mAP(pb, [r[:] for r in pb])) - float(golden("kat")["map_identical"])) <= 1e-6   # utils_test.py:22-32
+    with pytest.raises(ZeroDivisionError):
+        yt.calc_mAP(pb, [], num_classes=3)
+    # a big evaluation set: 128 images x ~80 kept boxes, must agree with the oracle restatement
+    from oracle import metrics as om
+    rng = np.random.Generator(np.random.PCG64(77))
+    preds, trues = [], []
+    for img in range(24):
+        for _ in range(6):
+            cls = int(rng.integers(0, 5))
+            b = [float(np.float32(v)) for v in (*rng.uniform(0.2, 0.8, 2), *rng.uniform(0.05, 0.3, 2))]
+            trues.append([img, *b, 1.0, cls])
+            for _ in range(3):
+                preds.append([img, *[float(np.float32(v + 0.02 * rng.standard_normal())) for v in b], float(np.float32(rng.uniform(0.2, 1))), cls])
+    assert abs(float(yt.calc_mAP(preds, trues, 0.5, "center", 5)) - float(om.calc_map(preds, trues, 0.5, "center", 5))) <= 2e-6

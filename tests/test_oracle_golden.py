@@ -216,3 +216,14 @@ def test_targets_oracle_equals_reference_getitem(golden, case):
             want = g[f"{case}/img{b}/scale{s_i}"]
             assert got[s_i].shape == want.shape
             np.testing.assert_array_equal(got[s_i].numpy(), want)
+
+
+# ------------------------------------------------------------------ mAP (utils.py:193-274)
+@pytest.mark.parametrize("case", list(gi.MAP_CASES))
+def test_map_oracle_vs_reference(golden, case):
+    from oracle import metrics as om
+    g = golden("kat")
+    pb, tb = gi.map_boxes(case)
+    nc = gi.MAP_CASES[case]["nc"]
+    assert abs(float(om.calc_map(pb, tb, 0.5, "center", nc)) - float(g[f"map_{case}"])) <= 1e-6
+    assert abs(float(om.calc_map(pb, tb, 0.75, "center", nc)) - float(g[f"map_{case}_iou75"])) <= 1e-6

@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
-           "detect", "build_targets"]
+           "detect", "build_targets", "calc_mAP"]
 
 
 # -------------------------------------------------------------------------------- IoU
@@ -186,3 +186,46 @@ def build_targets(boxes, anchors, image_size, counts=None, ignore_iou_threshold=
                                            outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), L.current_stream()),
                 "yolo_build_targets")
     return tuple(outs)
+
+
+# ------------------------------------------------------------------------------ mAP
+def calc_mAP(pred_boxes, true_boxes, iou_threshold=0.5, box_format="center", num_classes=20):
+    """Drop-in for the reference's ``calc_mAP`` (utils.py:193-274): rows ``[image_id, cx, cy, w, h, obj, class]``
+    (lists or tensors), returns the mean over the classes that have ground truth of the trapezoid area under the
+    precision/recall curve, as a 0-dim CPU tensor. The per-pair Python loop becomes two stable device sorts and
+    two kernels (sequential matching per class, AP integration)."""
+    dev = torch.device("cuda")
+    dets = torch.as_tensor(pred_boxes, dtype=torch.float32).reshape(-1, 7).to(dev)
+    gts = torch.as_tensor(true_boxes, dtype=torch.float32).reshape(-1, 7).to(dev)
+    nc = int(num_classes)
+
+    def class_rows(t):                                     # `box[-1] == c` for c in range(num_classes)
+        c = t[:, 6]
+        ok = (c >= 0) & (c < nc) & (c == torch.floor(c))
+        return t[ok]
+    dets, gts = class_rows(dets), class_rows(gts)
+    # detections: objectness descending, then class ascending — both stable, so ties keep list order (list.sort)
+    o = torch.sort(dets[:, 5], descending=True, stable=True).indices
+    o = o[torch.sort(dets[o, 6], stable=True).indices]
+    dets = dets[o].contiguous()
+    # ground truths: image ascending, then class ascending (stable): per (class, image) the list order survives
+    o = torch.sort(gts[:, 0], stable=True).indices
+    o = o[torch.sort(gts[o, 6], stable=True).indices]
+    gts = gts[o].contiguous()
+
+    def offsets(t):
+        cnt = torch.bincount(t[:, 6].long(), minlength=nc)[:nc]
+        return torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt, 0)]).to(torch.int32).contiguous()
+    d_off, g_off = offsets(dets), offsets(gts)
+    with torch.cuda.device(dev):
+        assigned = torch.empty(max(1, gts.shape[0]), dtype=torch.int32, device=dev)
+        tp = torch.zeros(max(1, dets.shape[0]), dtype=torch.float32, device=dev)
+        ap = torch.empty(nc, dtype=torch.float32, device=dev)
+        L.check(L.lib().yolo_map_match(dets.data_ptr(), d_off.data_ptr(), gts.data_ptr(), g_off.data_ptr(), nc, gts.shape[0],
+                                       float(iou_threshold), 1 if box_format == "center" else 0, assigned.data_ptr(), tp.data_ptr(),
+                                       ap.data_ptr(), L.current_stream()), "yolo_map_match")
+    ap = ap.cpu()
+    valid = ap >= 0
+    if not bool(valid.any()):
+        raise ZeroDivisionError("division by zero")        # the reference divides by len([]) here
+    return ap[valid].sum() / int(valid.sum())
