@@ -257,26 +257,9 @@ def main():
                     "algorithmic_tflops": round(3 * 65.297 * (args.size / 416.0) ** 2 * args.batch * world * args.train_steps / t_el / 1e3, 2)}
 
         def graph_leg(autocast_dtype):                  # the same step captured ONCE into a HIP graph and replayed
-            lf = yt.FusedYOLOLoss()
-            step = make_step(lf, autocast_dtype)
-            tm._engine.nan_check = False                # the per-forward NaN guard is a host sync
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            gph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(gph):
-                with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
-                    preds = tm(x)
-                loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
-                loss.backward()
-                opt.step()
-            t_el = ydist.timed_steps(gph.replay, args.train_steps, 2, dist, device)
-            tm._engine.nan_check = True
-            del gph
+            gstep = yt.GraphedTrainStep(tm, opt, sa, x, tg, autocast_dtype=autocast_dtype)
+            t_el = ydist.timed_steps(lambda: gstep(x, tg), args.train_steps, 2, dist, device)
+            del gstep
             return t_el
 
         def train_leg(autocast_dtype):

@@ -793,3 +793,46 @@ def test_map_known_answers(yt, golden):
             for _ in range(3):
                 preds.append([img, *[float(np.float32(v + 0.02 * rng.standard_normal())) for v in b], float(np.float32(rng.uniform(0.2, 1))), cls])
     assert abs(float(yt.calc_mAP(preds, trues, 0.5, "center", 5)) - float(om.calc_map(preds, trues, 0.5, "center", 5))) <= 2e-6
+
+
+# ------------------------------------------------------------- whole-step HIP graph
+@pytest.mark.parametrize("ac", [None, torch.bfloat16])
+def test_graphed_train_step_equals_eager_steps(yt, ac):
+    """GraphedTrainStep (forward + 3 fused losses + backward + SGD captured as one HIP graph) must walk the same
+    parameter trajectory as the same steps issued eagerly: every kernel is deterministic, so after warm-up (3 steps)
+    + 2 replays the weights are compared bit for bit with 5 eager steps on the same batches."""
+    nc, S, B = 2, 96, 2
+    anchors = gi.TRAIN_CASE["anchors"]
+    sd = onet.synth_state_dict(71, 3, nc, gain=gi.NET_GAIN)
+    sa = (torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)).cuda()
+    batches = [(onet.synth_input(80 + k, B, S).cuda(), [torch.from_numpy(t).cuda() for t in gi.synth_targets(B, S, nc, anchors, 90 + k)])
+               for k in range(3)]
+
+    def make():
+        m = yt.YOLOv3(num_classes=nc, activation="mish")
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        return m, torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    # eager: warm-up uses batch 0 three times, then batches 1 and 2
+    m1, o1 = make()
+    lf = yt.FusedYOLOLoss()
+    seq = [batches[0]] * 3 + [batches[1], batches[2]]
+    eager_losses = []
+    for x, tg in seq:
+        o1.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=ac or torch.bfloat16, enabled=ac is not None):
+            preds = m1(x)
+        loss = sum(sum(lf(preds[i], tg[i], sa[i])) for i in range(3))
+        loss.backward()
+        o1.step()
+        eager_losses.append(float(loss.detach()))
+    m2, o2 = make()
+    step = yt.GraphedTrainStep(m2, o2, sa, batches[0][0], batches[0][1], autocast_dtype=ac)
+    l1 = float(step(*batches[1]))
+    l2 = float(step(*batches[2]))
+    assert l1 == eager_losses[3] and l2 == eager_losses[4]
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert m2._engine.nan_check is True
+    with pytest.raises(ValueError):
+        step(torch.zeros(1, 3, S, S, device="cuda"), batches[1][1])

@@ -5,10 +5,11 @@ The on-disk directory is also reachable as ``yolo-for-turbines_amd`` (symlink; a
 legal Python identifier). Everything computes in ``libyolo_mi355x.so`` (hand-written gfx950 HIP);
 there is no CPU fallback.
 """
+from .graph import GraphedTrainStep
 from .loss import FusedYOLOLoss, YOLOLoss
 from .model import CNNBlock, ResidualBlock, ScalePredictionBlock, YOLOv3, layer_config
 from .utils import (build_targets, calc_iou, calc_mAP, cells_to_boxes, decode_boxes, detect, iou_aligned, nms_indices,
                     non_max_suppression)
 
-__all__ = ["YOLOLoss", "FusedYOLOLoss", "CNNBlock", "ResidualBlock", "ScalePredictionBlock", "YOLOv3", "layer_config", "calc_iou",
+__all__ = ["YOLOLoss", "FusedYOLOLoss", "GraphedTrainStep", "CNNBlock", "ResidualBlock", "ScalePredictionBlock", "YOLOv3", "layer_config", "calc_iou",
            "cells_to_boxes", "decode_boxes", "detect", "iou_aligned", "nms_indices", "non_max_suppression", "build_targets", "calc_mAP"]

@@ -1,0 +1,72 @@
+"""Whole-step HIP graph for fine-tuning: capture once, replay every step.
+
+The reference's step (`/root/reference/code/train.py:41-69`: autocast forward, three per-scale losses, backward,
+optimizer step) is ~1,000 kernel launches here, many of them a few microseconds long; issued from Python one by
+one the GPU idles between them. Every kernel of this package launches on the current stream, allocates nothing
+behind PyTorch's back and — with :class:`FusedYOLOLoss` and the per-forward NaN guard off — never waits for the host,
+so ``torch.cuda.graph`` can record the whole step into ONE HIP graph. Static shapes only: one graph per
+(batch, image size); multi-scale training keeps one per size.
+"""
+from __future__ import annotations
+
+import torch
+
+from .loss import FusedYOLOLoss
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(model, optimizer, scaled_anchors, x, targets)`` then ``loss = step(x, targets)``.
+
+    ``x``: (B,3,S,S) batch, ``targets``: the three (B,3,g,g,6) tensors of the loader, ``scaled_anchors``: (3,3,2) anchors
+    in grid units (`train.py:195-197`). The example batch passed to the constructor fixes the shapes and is used for
+    the warm-up steps on a side stream (so they DO update the model, like three ordinary steps). ``autocast_dtype``
+    (``torch.bfloat16`` / ``torch.float16`` / None) selects what `train.py:53` selects. Returns the summed loss as a
+    0-dim tensor that is overwritten by the next call.
+    """
+
+    def __init__(self, model, optimizer, scaled_anchors, x, targets, autocast_dtype=None, loss_fn=None, warmup=3,
+                 zero_grad=True):
+        if not x.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors (no CPU fallback)")
+        self.model, self.opt = model, optimizer
+        self.loss_fn = loss_fn if loss_fn is not None else FusedYOLOLoss()
+        self.autocast_dtype = autocast_dtype
+        self.anchors = [a.detach().to(x.device, torch.float32).contiguous() for a in scaled_anchors]
+        self.x = x.detach().clone()
+        self.targets = [t.detach().clone().float().contiguous() for t in targets]
+        self.zero_grad = zero_grad
+        self._nan_check = model._engine.nan_check
+        model._engine.nan_check = False                 # the guard reads a flag on the host: a sync, not capturable
+        try:
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):         # allocator warm-up, plan build, lazily created optimizer state
+                    self._step_body()
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            if self.zero_grad:
+                self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step_body(zero=False)
+        finally:
+            model._engine.nan_check = self._nan_check
+
+    def _step_body(self, zero=True):
+        if zero and self.zero_grad:
+            self.opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            preds = self.model(self.x)
+        loss = sum(sum(self.loss_fn(preds[i], self.targets[i], self.anchors[i])) for i in range(3))
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, x, targets):
+        if tuple(x.shape) != tuple(self.x.shape):
+            raise ValueError(f"this graph was captured for input shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x, non_blocking=True)
+        for dst, src in zip(self.targets, targets):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss
