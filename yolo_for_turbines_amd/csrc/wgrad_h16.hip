@@ -276,8 +276,11 @@ static WgradHPlan plan_wgrad_h(int n, int h, int w, int cin, int cout, int ks, i
     return q;
 }
 
+// cin need not be a multiple of 8 (the 3-channel stem): x is read in 8-channel pieces, so x_ld must cover cin rounded
+// up to 8 and the pad channels of x must be zero (the NHWC boundary copy zero-fills them). With few channels most of the
+// 64-wide ci tile is zeros, which only wastes matrix issue slots: that layer is bound by reading dz from HBM.
 bool wgrad_h16_eligible(int cin, int cout, int ks, int stride, int dz_ld, int dz_off, int x_ld, int x_off) {
-    if (cin < 32 || (cin & 7)) return false;
+    if (cin < 1 || x_ld < round_up(cin, 8)) return false;
     if (ks == 1 && stride != 1) return false;
     if ((dz_ld & 7) || (dz_off & 7) || (x_ld & 7) || (x_off & 7)) return false;
     if (dz_ld < round_up(cout, 8)) return false;

@@ -375,7 +375,7 @@ def forward_train(state, model, x):
         key = ("train", B, H, x.device.index, dt)
         plan = state._plans.get(key)
         if plan is None:
-            prog = build_network_program(model, B, H)
+            prog = build_network_program(model, B, H, ch_align=8 if dt != "fp32" else 4)   # 16-bit kernels read 8-channel pieces
             plan = TrainPlan(prog, x.device, dt)
             if dt != "fp32" and not plan.stem:
                 raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
