@@ -187,6 +187,11 @@ int yolo_map_match(const float* dets_sorted, const int32_t* det_class_offsets, c
                    int num_classes, int n_gt, float iou_threshold, int center, int32_t* assigned, float* tp_flags, float* ap_per_class,
                    void* stream);
 
+/* check_model_accuracy (utils.py:334-381) for one scale of one batch: counts5 += [class correct, n_obj, objectness correct
+ * on object cells, objectness correct on no-object cells, n_noobj]; pred / target as for yolo_loss_fwd. */
+int yolo_accuracy_counts(const float* pred, const int64_t* strides5, const float* target, int b, int g, int nc, float obj_threshold,
+                         unsigned long long* counts5, void* stream);
+
 /* ---- fused per-scale loss (optional replacement of YOLOLoss.forward, loss.py:29-81) -------- */
 /* pred (B,3,g,g,5+nc) fp32 through element strides; target (B,3,g,g,6) fp32 contiguous
  * [x_cell,y_cell,w_cells,h_cells,obj in {1,0,-1},class]; anchors (3,2) in grid units.

@@ -301,6 +301,27 @@ def gen_kat():
         pb, tb = gi.map_boxes(name)
         out[f"map_{name}"] = np.array(float(ref_utils.calc_mAP([r[:] for r in pb], [r[:] for r in tb], 0.5, "center", c["nc"])))
         out[f"map_{name}_iou75"] = np.array(float(ref_utils.calc_mAP([r[:] for r in pb], [r[:] for r in tb], 0.75, "center", c["nc"])))
+    # check_model_accuracy (utils.py:334-381) of the reference on a stub model that replays seeded predictions
+    import config as ref_config
+    ref_config.DEVICE = "cpu"
+    batches = gi.accuracy_batches()
+
+    class Stub:
+        def __init__(self):
+            self.k = -1
+
+        def eval(self):
+            pass
+
+        def train(self):
+            pass
+
+        def __call__(self, x):
+            self.k += 1
+            return [torch.from_numpy(p.copy()) for p in batches[self.k][2]]
+    loader = [(torch.from_numpy(x), [torch.from_numpy(t.copy()) for t in tg]) for x, tg, _ in batches]
+    acc = ref_utils.check_model_accuracy(Stub(), loader, gi.ACC_CASE["thr"])
+    out["accuracy"] = np.array([float(a) for a in acc], np.float32)
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
 
 

@@ -285,3 +285,32 @@ def map_boxes(case):
             preds.append([img, f(rng.uniform(0.1, 0.9)), f(rng.uniform(0.1, 0.9)), f(rng.uniform(0.05, 0.4)), f(rng.uniform(0.05, 0.4)),
                           f(rng.uniform(0.1, 0.9)), int(rng.integers(0, c["nc"]))])
     return preds, trues
+
+
+# -------------------------------------------------------------------- check_model_accuracy cases (utils.py:334-381)
+ACC_CASE = dict(nc=5, size=96, batches=3, batch=4, seed=601, thr=0.6)
+
+
+def accuracy_batches():
+    """Seeded loader content [(x, [t0,t1,t2]), ...] and the predictions a stub model returns for batch k. Objectness
+    logits within 1e-4 of logit(thr) are pushed away so that no implementation's last-bit sigmoid decides a count."""
+    c = ACC_CASE
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    S, nc = c["size"], c["nc"]
+    edge = float(np.log(c["thr"] / (1 - c["thr"])))
+    out = []
+    for k in range(c["batches"]):
+        tg = synth_targets(c["batch"], S, nc, TRAIN_CASE["anchors"], c["seed"] + 10 + k, mean_boxes=6)
+        preds = []
+        for t in tg:
+            p = rng.standard_normal(t.shape[:4] + (5 + nc,), dtype=F32) * 1.5
+            near = np.abs(p[..., 4] - edge) < 1e-4
+            p[..., 4][near] += 1e-2
+            obj = t[..., 4] == 1                      # make about 60 % of the object cells predict the right class
+            hit = obj & (rng.random(obj.shape) < 0.6)
+            cls = t[..., 5].astype(np.int64)
+            idx = np.nonzero(hit)
+            p[idx + (5 + cls[idx],)] += 6.0
+            preds.append(p)
+        out.append((np.zeros((c["batch"], 3, S, S), F32), tg, preds))
+    return out

@@ -836,3 +836,33 @@ def test_graphed_train_step_equals_eager_steps(yt, ac):
     assert m2._engine.nan_check is True
     with pytest.raises(ValueError):
         step(torch.zeros(1, 3, S, S, device="cuda"), batches[1][1])
+
+
+# ------------------------------------------------------------- check_model_accuracy (utils.py:334-381)
+def test_check_model_accuracy_vs_reference(yt, golden, capsys):
+    """The mirror (one fused counting kernel per scale) against the three accuracies the reference function returned for
+    a stub model replaying the same seeded predictions / targets; counts are integers, so the bar is equality."""
+    want = golden("kat")["accuracy"]
+    batches = gi.accuracy_batches()
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.k = -1
+
+        def forward(self, x):
+            self.k += 1
+            return [torch.from_numpy(p.copy()).cuda() for p in batches[self.k][2]]
+    stub = Stub().cuda().train()
+    loader = [(torch.from_numpy(x), [torch.from_numpy(t.copy()) for t in tg]) for x, tg, _ in batches]
+    got = yt.check_model_accuracy(stub, loader, gi.ACC_CASE["thr"])
+    assert stub.training                                   # restored
+    np.testing.assert_array_equal(np.array([float(a) for a in got], np.float32), want)
+    assert "Class accuracy is:" in capsys.readouterr().out
+    # the reference's permuted prediction view (non-contiguous) gives the same counters
+    x, tg, preds = batches[0]
+    a = yt.accuracy_counts([torch.from_numpy(p).cuda() for p in preds], [torch.from_numpy(t) for t in tg], 0.6)
+    b = yt.accuracy_counts([torch.from_numpy(np.ascontiguousarray(p.transpose(0, 1, 4, 2, 3))).cuda().permute(0, 1, 3, 4, 2) for p in preds],
+                           [torch.from_numpy(t) for t in tg], 0.6)
+    assert torch.equal(a, b)

@@ -79,6 +79,8 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p]),
     "yolo_map_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "yolo_accuracy_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p]),
     "yolo_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "yolo_loss_fwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

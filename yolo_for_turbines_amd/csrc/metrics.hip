@@ -126,6 +126,45 @@ __global__ __launch_bounds__(256) void map_ap_kernel(const float* __restrict__ t
     if (t == 0) ap[c] = (float)(area / 2.0);
 }
 
+// check_model_accuracy (utils.py:334-381) for one scale of one batch: five integer counters, accumulated with integer
+// atomics (order-independent, so still deterministic): [class correct, n_obj, obj correct, noobj correct, n_noobj].
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx,
+                                                       long long sk, const float* __restrict__ tgt, long long cells, int g, int nc,
+                                                       float thr, unsigned long long* __restrict__ counts) {
+    unsigned c_cls = 0, c_nobj = 0, c_obj = 0, c_noobj = 0, c_nnoobj = 0;
+    for (long long cell = blockIdx.x * 256LL + threadIdx.x; cell < cells; cell += (long long)gridDim.x * 256) {
+        const float t4 = tgt[cell * 6 + 4];
+        if (t4 != 1.f && t4 != 0.f) continue;
+        const int x = (int)(cell % g);
+        const long long r1 = cell / g;
+        const int y = (int)(r1 % g);
+        const long long r2 = r1 / g;
+        const float* q = pred + (r2 / 3) * sb + (r2 % 3) * sa + y * sy + x * sx;
+        const bool obj_pred = 1.f / (1.f + expf(-q[4 * sk])) > thr;
+        if (t4 == 1.f) {
+            int best = 0;
+            float bv = q[5 * sk];
+            for (int k = 1; k < nc; ++k) {                   // first maximum; NaN counts as maximum (torch.argmax)
+                const float v = q[(5 + k) * sk];
+                if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }
+            }
+            c_cls += (float)best == tgt[cell * 6 + 5];
+            c_nobj += 1;
+            c_obj += obj_pred;
+        } else {
+            c_noobj += !obj_pred;
+            c_nnoobj += 1;
+        }
+    }
+    unsigned v[5] = {c_cls, c_nobj, c_obj, c_noobj, c_nnoobj};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        unsigned s = v[k];
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(counts + k, (unsigned long long)s);
+    }
+}
+
 }  // namespace yolo
 
 using namespace yolo;
@@ -147,6 +186,18 @@ int yolo_map_match(const float* dets_sorted, const int32_t* det_class_offsets, c
     if (rc) return rc;
     hipLaunchKernelGGL(map_ap_kernel, dim3(num_classes), dim3(256), 0, s, tp_flags, det_class_offsets, gt_class_offsets, ap_per_class);
     return check_launch("map_ap");
+}
+
+int yolo_accuracy_counts(const float* pred, const int64_t* strides5, const float* target, int b, int g, int nc, float obj_threshold,
+                         unsigned long long* counts5, void* stream) {
+    if (!pred || !strides5 || !target || !counts5 || b <= 0 || g <= 0 || nc <= 0) return fail(YOLO_ERR_ARG, "accuracy: bad arguments");
+    const long long cells = (long long)b * 3 * g * g;
+    long long nb = (cells + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, (long long)strides5[0],
+                       (long long)strides5[1], (long long)strides5[2], (long long)strides5[3], (long long)strides5[4], target, cells, g, nc,
+                       obj_threshold, counts5);
+    return check_launch("accuracy");
 }
 
 }  // extern "C"
