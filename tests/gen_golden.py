@@ -322,6 +322,19 @@ def gen_kat():
     loader = [(torch.from_numpy(x), [torch.from_numpy(t.copy()) for t in tg]) for x, tg, _ in batches]
     acc = ref_utils.check_model_accuracy(Stub(), loader, gi.ACC_CASE["thr"])
     out["accuracy"] = np.array([float(a) for a in acc], np.float32)
+    # get_eval_boxes (utils.py:276-332) of the reference on a stub model replaying seeded predictions
+    ebatches = gi.eval_batches()
+
+    class EStub(Stub):
+        def __call__(self, x):
+            self.k += 1
+            return [torch.from_numpy(p.copy()) for p in ebatches[self.k][2]]
+    eloader = [(torch.from_numpy(x), [torch.from_numpy(t.copy()) for t in tg]) for x, tg, _ in ebatches]
+    ec = gi.EVAL_CASE
+    pb, tb = ref_utils.get_eval_boxes(eloader, EStub(), ec["iou_thr"], ec["anchors"], ec["obj_thr"], "center", "cpu")
+    out["eval_pred_boxes"] = np.asarray(pb, np.float64).reshape(-1, 7)
+    out["eval_true_boxes"] = np.asarray(tb, np.float64).reshape(-1, 7)
+    out["eval_map"] = np.array(float(ref_utils.calc_mAP(pb, tb, 0.5, "center", ec["nc"])))
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
 
 

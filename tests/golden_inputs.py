@@ -314,3 +314,27 @@ def accuracy_batches():
             preds.append(p)
         out.append((np.zeros((c["batch"], 3, S, S), F32), tg, preds))
     return out
+
+
+# -------------------------------------------------------------------- get_eval_boxes case (utils.py:276-332)
+EVAL_CASE = dict(nc=4, size=64, batches=2, batch=2, seed=701, iou_thr=0.45, obj_thr=0.5, anchors=COCO_ANCHORS)
+
+
+def eval_batches():
+    """Loader content and the predictions of a stub model for get_eval_boxes: small grids (2, 4, 8) so that the reference's
+    Python NMS stays fast; objectness logits pushed away from the threshold's logit."""
+    c = EVAL_CASE
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    S, nc = c["size"], c["nc"]
+    out = []
+    for k in range(c["batches"]):
+        tg = synth_targets(c["batch"], S, nc, c["anchors"], c["seed"] + 10 + k, mean_boxes=3)
+        preds = []
+        for t in tg:
+            p = (rng.standard_normal(t.shape[:4] + (5 + nc,), dtype=F32) * 0.8).astype(F32)
+            p[..., 4] -= 1.0                                             # ~25 % of the cells pass the objectness threshold
+            near = np.abs(p[..., 4]) < 1e-3
+            p[..., 4][near] += 1e-2
+            preds.append(p)
+        out.append((np.zeros((c["batch"], 3, S, S), F32), tg, preds))
+    return out

@@ -866,3 +866,34 @@ def test_check_model_accuracy_vs_reference(yt, golden, capsys):
     b = yt.accuracy_counts([torch.from_numpy(np.ascontiguousarray(p.transpose(0, 1, 4, 2, 3))).cuda().permute(0, 1, 3, 4, 2) for p in preds],
                            [torch.from_numpy(t) for t in tg], 0.6)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------- get_eval_boxes (utils.py:276-332)
+def test_get_eval_boxes_vs_reference(yt, golden):
+    """Whole evaluation path — forward (stub replaying seeded predictions), decode of three scales, per-image NMS, image
+    ids, ground-truth extraction from targets[2] — against the two box lists the reference's get_eval_boxes returned:
+    same rows in the same order; then calc_mAP of those lists equals the reference's calc_mAP of its lists."""
+    g = golden("kat")
+    ec = gi.EVAL_CASE
+    batches = gi.eval_batches()
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.k = -1
+
+        def forward(self, x):
+            self.k += 1
+            return [torch.from_numpy(p.copy()).cuda() for p in batches[self.k][2]]
+    stub = Stub().cuda()
+    loader = [(torch.from_numpy(x), [torch.from_numpy(t.copy()) for t in tg]) for x, tg, _ in batches]
+    pb, tb = yt.get_eval_boxes(loader, stub, ec["iou_thr"], ec["anchors"], ec["obj_thr"], "center")
+    want_p, want_t = g["eval_pred_boxes"], g["eval_true_boxes"]
+    got_p, got_t = np.asarray(pb, np.float64).reshape(-1, 7), np.asarray(tb, np.float64).reshape(-1, 7)
+    assert got_p.shape == want_p.shape and got_t.shape == want_t.shape
+    np.testing.assert_array_equal(got_p[:, [0, 6]], want_p[:, [0, 6]])          # image ids and classes: same rows, same order
+    np.testing.assert_allclose(got_p, want_p, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got_t, want_t, rtol=1e-6, atol=1e-7)
+    assert abs(float(yt.calc_mAP(pb, tb, 0.5, "center", ec["nc"])) - float(g["eval_map"])) <= 1e-6
+    assert stub.training                                                          # utils.py:331 leaves the model in train mode

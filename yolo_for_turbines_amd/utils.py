@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
-           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy"]
+           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy", "eval_boxes", "get_eval_boxes"]
 
 
 # -------------------------------------------------------------------------------- IoU
@@ -275,3 +275,46 @@ def check_model_accuracy(model, loader, object_threshold):
     if was_training:
         model.train()
     return class_accuracy, noobj_accuracy, obj_accuracy
+
+
+# ------------------------------------------------------------------------------ evaluation boxes
+def eval_boxes(loader, model, iou_threshold, anchors, obj_threshold, box_format="center"):
+    """Device-resident ``get_eval_boxes`` (utils.py:276-332): per batch one forward, one fused decode + batched NMS
+    (:func:`detect`) and one decode of the last-scale targets; returns two tensors of rows
+    ``[image_id, cx, cy, w, h, obj, class]`` — kept predictions in the reference's order (image by image,
+    objectness-descending) and ground-truth boxes (cells of ``targets[2]`` with objectness > ``obj_threshold``).
+    Feed them straight to :func:`calc_mAP`."""
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    preds_out, trues_out = [], []
+    data_idx = 0
+    for x, targets in loader:
+        with torch.no_grad():
+            predictions = model(x.to(dev))
+        B = x.shape[0]
+        sa = [torch.as_tensor(anchors[i], dtype=torch.float32, device=dev).reshape(3, 2) * predictions[i].shape[2] for i in range(3)]
+        boxes, keep, count = detect(predictions, sa, iou_threshold, obj_threshold, box_format)
+        g = predictions[2].shape[2]
+        true_boxes = decode_boxes(targets[2].to(dev, torch.float32).contiguous(), sa[2], g, is_pred=False)     # (B, 3 g^2, 6)
+        cnt = count.tolist()
+        for b in range(B):
+            kb = boxes[b, keep[b, :cnt[b]].long()]
+            ids = torch.full((kb.shape[0], 1), float(data_idx + b), device=dev)
+            preds_out.append(torch.cat([ids, kb], 1))
+            tb = true_boxes[b][true_boxes[b][:, 4] > obj_threshold]
+            trues_out.append(torch.cat([torch.full((tb.shape[0], 1), float(data_idx + b), device=dev), tb], 1))
+        data_idx += B
+    if was_training:
+        model.train()
+    empty = torch.zeros((0, 7), device=dev)
+    return (torch.cat(preds_out) if preds_out else empty), (torch.cat(trues_out) if trues_out else empty)
+
+
+def get_eval_boxes(loader, model, iou_threshold, anchors, obj_threshold, box_format="center", device=None):
+    """Drop-in for the reference's ``get_eval_boxes`` (utils.py:276-332): same arguments, same two Python lists of
+    ``[image_id, cx, cy, w, h, obj, class]`` rows. (``device`` is accepted for signature compatibility; the model's
+    device is used.) It leaves the model in train mode like the reference (utils.py:331)."""
+    p, t = eval_boxes(loader, model, iou_threshold, anchors, obj_threshold, box_format)
+    model.train()
+    return p.tolist(), t.tolist()
