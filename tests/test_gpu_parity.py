@@ -897,3 +897,26 @@ def test_get_eval_boxes_vs_reference(yt, golden):
     np.testing.assert_allclose(got_t, want_t, rtol=1e-6, atol=1e-7)
     assert abs(float(yt.calc_mAP(pb, tb, 0.5, "center", ec["nc"])) - float(g["eval_map"])) <= 1e-6
     assert stub.training                                                          # utils.py:331 leaves the model in train mode
+
+
+# ------------------------------------------------------------- RCCL path with one rank
+def test_bench_runs_over_rccl_with_one_rank(tmp_path):
+    """The multi-GPU path (process group over RCCL, bucketed asynchronous gradient all-reduce inside backward,
+    barrier + max-over-ranks timing) exercised end to end with a 1-rank group in a child process; the 8-GPU run is
+    the driver's. Checks the one-JSON-line contract and that the data-parallel fine-tune leg produced numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YOLO_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--size", "160", "--train-steps", "2", "--no-cpu-baseline", "--no-nms", "--no-config5", "--no-config3"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["train"]["value"] > 0 and d["train"]["bf16_autocast"]["value"] > 0
