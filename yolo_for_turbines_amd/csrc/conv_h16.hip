@@ -50,7 +50,7 @@ struct ConvHArgs {
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
     // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
     // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
-    unsigned mg_H, mg_TW, mg_PC, mg_tn, mg_tw;
+    unsigned mg_H, mg_TW, mg_PC, mg_tn, mg_tw, mg_Hp;
 };
 
 // x / d for 0 <= x < 2^31 with mg = ceil(2^32 / d) (d >= 2) or 0 (d == 1): the estimate is q or q + 1, one fix-up
@@ -342,17 +342,17 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
 
     HCtx<T, TN> c;
     c.KT = p.KT;
-    {   // staged patch pixels of this 4-lane group: idx = (tid >> 2) + 64 i
-        const int d_pr = fdiv(64, p.mg_PC, p.PC), d_pc = 64 - d_pr * p.PC;
-        int pr = fdiv(tid >> 2, p.mg_PC, p.PC), pc = (tid >> 2) - pr * p.PC;
-        const int n0i = KS == 3 ? fdiv(g0, p.mg_H, p.H) : 0;            // image of the tile's first row (v0 / Hp)
+    {   // staged patch pixels of this 4-lane group: idx = (tid >> 2) + 64 i. Closed form per entry (two magic divisions):
+        // the incremental version with carry loops was ~800 VALU instructions, 4-6k cycles of a 10k-cycle prologue
 #pragma unroll
         for (int i = 0; i < H_NI; ++i) {
+            const int idx = (tid >> 2) + 64 * i;
+            const int pr = fdiv(idx, p.mg_PC, p.PC), pc = idx - pr * p.PC;
             int pix = -1;
             if (pr < PR) {
                 if (KS == 3) {
-                    int n = n0i, yy = v0 + pr - n0i * Hp;
-                    while (yy >= Hp) { yy -= Hp; ++n; }
+                    const int vv = v0 + pr;
+                    const int n = fdiv(vv, p.mg_Hp, Hp), yy = vv - n * Hp;
                     const int hi = yy - 1, wi = STRIDE * c0 + pc - 1;
                     if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) pix = (n * p.Hin + hi) * p.Win + wi;
                 } else {
@@ -361,8 +361,6 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
                 }
             }
             c.pix[i] = pix;
-            pr += d_pr; pc += d_pc;
-            while (pc >= p.PC) { pc -= p.PC; ++pr; }
         }
     }
 #pragma unroll
@@ -709,7 +707,7 @@ int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtyp
 
 static void fill_magics(ConvHArgs& a) {
     a.mg_H = magic_of(a.H); a.mg_TW = magic_of(a.TW); a.mg_PC = magic_of(a.PC);
-    a.mg_tn = magic_of(a.tiles_n); a.mg_tw = magic_of(a.tiles_w);
+    a.mg_tn = magic_of(a.tiles_n); a.mg_tw = magic_of(a.tiles_w); a.mg_Hp = magic_of(a.Hin + 2);
 }
 
 static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax) {
