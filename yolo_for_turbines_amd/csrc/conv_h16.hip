@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nt = n_tile * (BN / 32) + wn * TN + j;
+        const int nt = n_tile * (BN / 32) + j * 2 + wn;          // pass j of the epilogue = 64 CONTIGUOUS channels (full 128-B lines)
         c.wfrag[j] = p.wf + (size_t)nt * p.KT * 1024 + lane * 8;
     }
 
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         {
-            const int n = n_tile * BN + wn * (BN / 2) + j * 32 + frow;
+            const int n = n_tile * BN + j * 64 + wn * 32 + frow;
             const bool nv = n < p.Cout;
             const float sc = nv ? (MASK ? 1.f : p.scale[n]) : 0.f;       // gradient kernels: plain accumulation
             const float sh = nv ? (MASK ? 0.f : p.shift[n]) : 0.f;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
                 const int idx = tid + 256 * it;
                 const int row = idx >> 3, c8 = idx & 7;
                 const int m = mtab[row];
-                const int n = n_tile * BN + (c8 >> 2) * (BN / 2) + j * 32 + (c8 & 3) * 8;
+                const int n = n_tile * BN + j * 64 + c8 * 8;
                 if (m < 0 || n >= p.Cout) continue;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8 + 4);
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
                 const int idx = tid + 256 * it;
                 const int row = idx >> 6, col = idx & 63;
                 const int m = mtab[row];
-                const int n = n_tile * BN + (col >> 5) * (BN / 2) + j * 32 + (col & 31);
+                const int n = n_tile * BN + j * 64 + col;
                 if (m < 0 || n >= p.Cout) continue;
                 float v = ost[row * OLD + col];
                 if (has_res) v += HTraits<T>::to_f32(p.res[(size_t)m * p.r_ld + p.r_off + n]);
