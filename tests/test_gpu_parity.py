@@ -920,3 +920,37 @@ def test_bench_runs_over_rccl_with_one_rank(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["train"]["value"] > 0 and d["train"]["bf16_autocast"]["value"] > 0
+
+
+def test_train_mode_single_value_per_channel_is_rejected(yt):
+    """nn.BatchNorm2d refuses batch statistics over one value (B = 1 at S = 32 leaves a 1x1 map): same ValueError."""
+    m = yt.YOLOv3(num_classes=2).cuda().train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(torch.rand(1, 3, 32, 32, device="cuda"))
+
+
+@pytest.mark.parametrize("S,B,nc", [(96, 5, 3), (224, 1, 2)])
+def test_network_train_step_odd_shapes_vs_oracle(yt, S, B, nc):
+    """Odd batch sizes / a single image / a non-square-of-two grid through the whole fp32 train step (fused loss):
+    every parameter gradient within 2e-4 relative L2 of the oracle under CPU autograd."""
+    from oracle import loss as oloss
+    anchors = gi.TRAIN_CASE["anchors"]
+    sd = onet.synth_state_dict(5, 3, nc, gain=gi.NET_GAIN)
+    x = onet.synth_input(S + B, B, S)
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(B, S, nc, anchors, 3)]
+    sa = torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)
+    par = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd)
+    full.update(par)
+    pr = onet.forward(full, x, nc, "mish", training=True, new_stats={})
+    sum(sum(oloss.yolo_loss(pr[i], tg[i].clone(), sa[i])) for i in range(3)).backward()
+    m = yt.YOLOv3(num_classes=nc, activation="mish")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    lf = yt.FusedYOLOLoss()
+    po = m(x.cuda())
+    sum(sum(lf(po[i], tg[i].cuda(), sa[i].cuda())) for i in range(3)).backward()
+    for k, p in m.named_parameters():
+        g, r = p.grad.cpu().double().reshape(-1), par[k].grad.double().reshape(-1)
+        if float(r.norm()) > 1e-12:
+            assert float((g - r).norm() / r.norm()) < 2e-4, k

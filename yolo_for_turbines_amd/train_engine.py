@@ -64,6 +64,9 @@ class TrainPlan:
         for op in prog.ops:
             blk, cv = op["block"], op["block"].conv
             m = self.B * op["Ho"] * op["Wo"]
+            if blk.batch_norm_act and m <= 1:                   # nn.BatchNorm2d in train mode refuses this too
+                raise ValueError("Expected more than 1 value per channel when training, got input size "
+                                 f"torch.Size([{self.B}, {cv.out_channels}, {op['Ho']}, {op['Wo']}])")
             if blk.batch_norm_act:
                 self.z.append(torch.empty(m * cv.out_channels, **act))
                 self.stats.append(torch.empty(4, cv.out_channels, **f32))        # mean, invstd, scale, shift
