@@ -170,6 +170,11 @@ int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_pack
 /* upstream gradient in the head layout (B,3,g,g,D) fp32, any strides -> NHWC (B,g,g,ld) in dtype, channel a*D+k, pads 0 */
 int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream);
 
+/* ---- letterbox (config.py:101-113: LongestMaxSize -> centred PadIfNeeded(0) -> /255 -> CHW); parity with cv2 UNPINNED --- */
+/* img: uint8 (h, w, 3) on the device; out: fp32 (3, size, size). new_hw / pad_tl (host pointers, may be NULL) receive the
+ * resized size and the top / left padding, which un-letterboxing the boxes needs (utils.py:475-501). */
+int yolo_letterbox(const unsigned char* img_hwc, int h, int w, int size, float* out_chw, int* new_hw, int* pad_tl, void* stream);
+
 /* ---- ground-truth tensors (next to the hot path: dataset.py:119-161) ------------------------ */
 /* boxes (B, max_boxes, 5) fp32 [x, y, w, h, class] normalised to [0,1), counts (B) valid boxes per image (list order
  * matters), anchors (9,2) normalised and scale-major (config.ANCHORS flattened). Writes the three target tensors

@@ -954,3 +954,21 @@ def test_network_train_step_odd_shapes_vs_oracle(yt, S, B, nc):
         g, r = p.grad.cpu().double().reshape(-1), par[k].grad.double().reshape(-1)
         if float(r.norm()) > 1e-12:
             assert float((g - r).norm() / r.norm()) < 2e-4, k
+
+
+# ------------------------------------------------------------- letterbox (config.py:101-113) — parity UNPINNED
+@pytest.mark.parametrize("h,w,size", [(480, 640, 416), (375, 500, 416), (1080, 1920, 608), (416, 416, 416), (200, 333, 416), (900, 37, 96)])
+def test_letterbox_vs_restatement(yt, h, w, size):
+    """Device letterbox against oracle/preprocess.py (a restatement of OpenCV's uint8 INTER_LINEAR and albumentations'
+    size / padding rules; cv2 itself is not installed here, so parity with the reference transform is unpinned):
+    bit-exact output, same geometry; up- and down-scaling, no-op size, extreme aspect ratio."""
+    from oracle import preprocess as opre
+    rng = np.random.Generator(np.random.PCG64(h * 7 + w))
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    want, meta_w = opre.letterbox(img, size)
+    got, meta = yt.letterbox([img], size)
+    assert tuple(got.shape) == (1, 3, size, size) and got.dtype == torch.float32
+    assert tuple(meta[0]) == tuple(meta_w)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want)
+    boxes = [[0.5, 0.5, 0.2, 0.3, 0.9, 1.0], [0.1, 0.8, 0.05, 0.1, 0.7, 0.0]]
+    assert yt.unletterbox_boxes(boxes, (h, w), (size, size)) == opre.unletterbox_boxes(boxes, (h, w), (size, size))

@@ -227,3 +227,20 @@ def test_map_oracle_vs_reference(golden, case):
     nc = gi.MAP_CASES[case]["nc"]
     assert abs(float(om.calc_map(pb, tb, 0.5, "center", nc)) - float(g[f"map_{case}"])) <= 1e-6
     assert abs(float(om.calc_map(pb, tb, 0.75, "center", nc)) - float(g[f"map_{case}_iou75"])) <= 1e-6
+
+
+def test_letterbox_restatement_is_sane():
+    """oracle/preprocess.py (parity with cv2 unpinned): geometry rules and the fixed-point bilinear within one grey level
+    of a float bilinear resize; identity when the image already has the target size."""
+    from oracle import preprocess as opre
+    rng = np.random.Generator(np.random.PCG64(3))
+    img = rng.integers(0, 256, (375, 500, 3), dtype=np.uint8)
+    out, (h, w, nh, nw, top, left) = opre.letterbox(img, 416)
+    assert (nh, nw, top, left) == (312, 416, 52, 0) and out.shape == (3, 416, 416)
+    assert float(out[:, :top].max()) == 0.0 and float(out[:, top + nh:].max()) == 0.0
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+    ref = torch.nn.functional.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(opre.resize_linear_u8(img, nh, nw).astype(np.float32) - ref).max() <= 1.0
+    sq = rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)
+    o2, _ = opre.letterbox(sq, 96)
+    np.testing.assert_array_equal(o2, sq.transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255))

@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
-           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy", "eval_boxes", "get_eval_boxes"]
+           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy", "eval_boxes", "get_eval_boxes", "letterbox", "unletterbox_boxes"]
 
 
 # -------------------------------------------------------------------------------- IoU
@@ -318,3 +318,43 @@ def get_eval_boxes(loader, model, iou_threshold, anchors, obj_threshold, box_for
     p, t = eval_boxes(loader, model, iou_threshold, anchors, obj_threshold, box_format)
     model.train()
     return p.tolist(), t.tolist()
+
+
+# ------------------------------------------------------------------------------ letterbox
+def letterbox(images, image_size=416, device=None):
+    """``config.set_only_image_transforms`` (config.py:101-113) on the device: each uint8 (H, W, 3) image (tensor or
+    array) is resized so that its longer side is ``image_size`` (bilinear), centred on a zero canvas, scaled to [0,1]
+    and laid out CHW. Returns ``(batch (B,3,S,S) fp32, meta)`` with ``meta[i] = (orig_h, orig_w, new_h, new_w,
+    pad_top, pad_left)`` for :func:`unletterbox_boxes`. Parity with cv2 is unpinned (see csrc/preprocess.hip)."""
+    if isinstance(images, (torch.Tensor,)) and images.dim() == 3 or not isinstance(images, (list, tuple)):
+        images = [images]
+    dev = torch.device("cuda" if device is None else device)
+    if dev.type != "cuda":
+        raise RuntimeError("letterbox runs on MI355X only (no CPU fallback)")
+    S = int(image_size)
+    with torch.cuda.device(dev):
+        out = torch.empty((len(images), 3, S, S), dtype=torch.float32, device=dev)
+        meta = []
+        for i, im in enumerate(images):
+            t = torch.as_tensor(im)
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise ValueError("images must be uint8 (H, W, 3)")
+            t = t.to(dev).contiguous()
+            nhw, pad = (C.c_int * 2)(), (C.c_int * 2)()
+            L.check(L.lib().yolo_letterbox(t.data_ptr(), t.shape[0], t.shape[1], S, out[i].data_ptr(), nhw, pad, L.current_stream()),
+                    "yolo_letterbox")
+            t.record_stream(torch.cuda.current_stream())
+            meta.append((int(t.shape[0]), int(t.shape[1]), nhw[0], nhw[1], pad[0], pad[1]))
+    return out, meta
+
+
+def unletterbox_boxes(boxes, original_hw, resized_hw):
+    """Box mapping of ``plot_original`` (utils.py:475-501): normalised letterboxed ``[cx, cy, w, h, obj, cls]`` rows ->
+    coordinates normalised to the ORIGINAL image. Same arithmetic (incl. its ``int(o * scale)`` size and ``// 2`` padding)."""
+    o_h, o_w = original_hw
+    r_h, r_w = resized_hw
+    scale = min(r_w / o_w, r_h / o_h)
+    new_width, new_height = int(o_w * scale), int(o_h * scale)
+    pad_width, pad_height = (r_w - new_width) // 2, (r_h - new_height) // 2
+    return [[(b[0] * r_w - pad_width) / new_width, (b[1] * r_h - pad_height) / new_height, (b[2] * r_w) / new_width,
+             (b[3] * r_h) / new_height, b[4], b[5]] for b in boxes]
