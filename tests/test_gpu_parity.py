@@ -54,7 +54,7 @@ def test_conv_block_eval_vs_golden(yt, golden, i):
         assert abs(float(y.double().abs().sum()) - s[1]) <= 1e-5 * s[1]
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("i", [0, 1, 2, 3, 7, 9, 10, 11, 15, 16, 18, 21, 22, 24])
 def test_conv_block_every_tile_vs_oracle(yt, i, tile):
     """Full-tensor check of each tile shape against the oracle (not only the sampled golden)."""

@@ -172,7 +172,7 @@ size_t v2_frag_elems(int cout, int cin, int ks);
 int v2_blocks(const yolo_conv_desc* d, int bn);          // grid size the patch kernel would launch
 int v2_pack(const float* w_oihw, float* wf, int cout, int cin, int ks, hipStream_t s);
 int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
-                   const void* residual, void* y, int32_t* nan_flag, int bn, hipStream_t s);
+                   const void* residual, void* y, int32_t* nan_flag, int bn, bool single_buffer, hipStream_t s);
 // conv_h16.hip (bf16 / fp16 patch kernel)
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 // ------------------------------------------------------------------------------ host side
 struct TileCfg { int bm, bn; };
 static const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
-constexpr int kNumTiles = 6;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128
+constexpr int kNumTiles = 7;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU)
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }
 
@@ -240,8 +240,13 @@ static int launch_tile(const ConvArgs& a, bool smallc, hipStream_t s) {
 // stride-1 layers with cin % 32 == 0 go to the patch/fragment-stream kernel (ids 5, 6).
 static int pick_tile(const yolo_conv_desc* d) {
     if (v2_eligible(d) && d->ksize == 3) {
-        // BN = 128 halves the A-fragment LDS reads per MFMA but needs enough blocks to fill 2 per CU
-        return (d->cout > 64 && v2_blocks(d, 128) >= 640) ? 6 : 5;
+        // Measured (tools/conv_bench.py --tile 5,6,7, batch 32): BN = 64 with ONE patch buffer (tile 7: 37 KB of LDS,
+        // 148 registers -> 3 blocks per CU instead of 2, one extra barrier per 32-channel chunk) wins by 4-16 % at 208x208,
+        // 104x104, 52x52 and 13x13 — three co-resident blocks cover each other's prologue/epilogue and 752 blocks fill
+        // 768 slots in one round at 13x13. At 26x26 (K = 2304, 1440 such blocks) BN = 128 with two buffers stays 9 % ahead.
+        const int ho = d->h;
+        if (d->cout > 64 && ho <= 26 && ho > 13 && v2_blocks(d, 128) >= 640) return 6;
+        return 7;
     }
     return 4;       // 1x1 (few K steps, prologue-dominated) and stride-2 layers: 64x64 register-staged tile
 }
@@ -290,7 +295,7 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     if (t >= 5) {
         if (!v2_eligible(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile %d needs stride 1 and cin %% 32 == 0", t);
         const float* wf = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize);
-        return conv_v2_launch(d, x, wf, scale, shift, residual, y, nan_flag, t == 6 ? 128 : 64, s);
+        return conv_v2_launch(d, x, wf, scale, shift, residual, y, nan_flag, t == 6 ? 128 : 64, t == 7, s);
     }
     switch (t) {
         case 1: return launch_tile<128, 128>(a, smallc, s);

@@ -39,6 +39,7 @@ struct Conv2Args {
     int Cin, Cout;
     int x_ld, x_off, y_ld, y_off, r_ld, r_off;
     int TH, TW, PC, patch_cap;  // tile rows/cols, patch columns, LDS pixels per buffer
+    int bufmask;                // 1: two patch buffers (2 blocks/CU); 0: one buffer + an extra barrier per chunk (3 blocks/CU at BN = 64)
     int tiles_w, tiles_n, nblocks;
     int KT, nchunks;
     int act, out_mode, flags, nc5;
@@ -93,10 +94,10 @@ __device__ __forceinline__ void v2_kstep(const Conv2Args& p, const V2Ctx<KS, TN>
     // next to their first use (lower register pressure) and the whole latency is exposed again
     __builtin_amdgcn_sched_barrier(0);
     constexpr int kh = TAP / KS, kw = TAP % KS;
-    const float* Ab = patch + (chunk & 1) * (p.patch_cap * V2_LD) + (kh * p.PC + kw) * V2_LD;
+    const float* Ab = patch + (chunk & p.bufmask) * (p.patch_cap * V2_LD) + (kh * p.PC + kw) * V2_LD;
     // A fragments are read from LDS one sub-step ahead of their MFMAs (`af` = sub-step 0 on entry)
     constexpr int nkh = (TAP + 1) / KS, nkw = (TAP + 1) % KS;
-    const float* Ab_next = patch + (chunk & 1) * (p.patch_cap * V2_LD) + (nkh * p.PC + nkw) * V2_LD;
+    const float* Ab_next = patch + (chunk & p.bufmask) * (p.patch_cap * V2_LD) + (nkh * p.PC + nkw) * V2_LD;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         f32x4 n0 = af[0], n1 = af[1];
@@ -118,14 +119,15 @@ __device__ __forceinline__ void v2_kstep(const Conv2Args& p, const V2Ctx<KS, TN>
         af[1] = n1;
     }
     if (TAP == TAPS - 1) {                     // chunk boundary (the last chunk stores a dummy patch)
-        float* dst = patch + ((chunk + 1) & 1) * (p.patch_cap * V2_LD) + (tid >> 3) * V2_LD + (tid & 7) * 4;
+        if (p.bufmask == 0) __syncthreads();   // single buffer: every wave must be done reading this chunk's patch
+        float* dst = patch + ((chunk + 1) & p.bufmask) * (p.patch_cap * V2_LD) + (tid >> 3) * V2_LD + (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < V2_NI; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if ((tid >> 3) + 32 * i < p.patch_cap) *reinterpret_cast<f32x4*>(dst + 32 * i * V2_LD) = c.pix[i] < 0 ? z : stage[i];
         }
         __syncthreads();
-        const float* An = patch + ((chunk + 1) & 1) * (p.patch_cap * V2_LD);       // tap 0 of the new chunk
+        const float* An = patch + ((chunk + 1) & p.bufmask) * (p.patch_cap * V2_LD);       // tap 0 of the new chunk
         af[0] = *reinterpret_cast<const f32x4*>(An + c.a_off[0]);
         af[1] = *reinterpret_cast<const f32x4*>(An + c.a_off[1]);
     }
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
     constexpr int TN = BN / 64;          // 32-wide n tiles per wave (wave tile 64 x BN/2)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* patch = reinterpret_cast<float*>(smem_raw);      // [2][patch_cap][V2_LD]
-    int* mtab = reinterpret_cast<int*>(patch + 2 * p.patch_cap * V2_LD);   // [128] MFMA row -> output pixel (or -1)
+    int* mtab = reinterpret_cast<int*>(patch + (p.bufmask + 1) * p.patch_cap * V2_LD);   // [128] MFMA row -> output pixel (or -1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -462,16 +464,16 @@ static int launch_v2(Conv2Args& a, hipStream_t s) {
     const int tiles_r = ceil_div(a.rows_total, a.TH);
     a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
     // resident blocks per CU (2 with these register/LDS footprints) x 256 CUs are dispatched at once
-    a.first_wave = 2 * 256;
+    a.first_wave = (a.bufmask ? 2 : 3) * 256;
     const long mfma_cycles = (long)a.KT * 32 * (BN / 64) * 64;  // one block's matrix work per wave
     a.stagger = g_v2_stagger ? (int)((mfma_cycles + 64 * 127 / 2) / (64 * 127)) : 0;
-    const size_t lds = (size_t)2 * a.patch_cap * V2_LD * sizeof(float) + 128 * sizeof(int);   // >= 128*68*4 staging (patch_cap >= 128)
+    const size_t lds = (size_t)(a.bufmask + 1) * a.patch_cap * V2_LD * sizeof(float) + 128 * sizeof(int);   // >= 128*68*4 staging
     hipLaunchKernelGGL((conv_patch_f32<KS, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_f32");
 }
 
 int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
-                   const void* residual, void* y, int32_t* nan_flag, int bn, hipStream_t s) {
+                   const void* residual, void* y, int32_t* nan_flag, int bn, bool single_buffer, hipStream_t s) {
     Conv2Args a;
     a.x = (const float*)x; a.wf = wf; a.scale = scale; a.shift = shift; a.res = (const float*)residual;
     a.y = (float*)y; a.nan_flag = nan_flag;
@@ -489,8 +491,10 @@ int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, cons
         pick_patch_tile(d->h, d->w, 3, &a.TH, &a.TW, &prmax);
         a.PC = a.TW + 2;
     }
+    a.bufmask = single_buffer ? 0 : 1;
     a.patch_cap = round_up(prmax * a.PC, 32);
     if (a.patch_cap < 128) a.patch_cap = 128;              // the epilogue stages a 128 x 68 float tile in the patch region
+    if (single_buffer) a.patch_cap = V2_PATCH_CAP;         // ... which then needs the whole (single) buffer: 256 px x 144 B = 36.9 KB
     if (a.patch_cap > V2_PATCH_CAP) return fail(YOLO_ERR_UNSUPPORTED, "conv v2: patch too large");
     a.tiles_w = ceil_div(a.W, a.TW);
     a.nchunks = d->cin / 32;
