@@ -167,6 +167,55 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
     bool saw_nan = false;
+    // NHWC outputs with cout % 4 == 0 (every BN block): scale/shift/activation in registers, transpose the BM x BN tile
+    // through the (now idle) operand LDS, and let every lane move 16 contiguous bytes of one pixel row. The direct stores
+    // below are 4-byte pieces of different rows per lane; on the short 1x1 blocks they were most of the block's life.
+    const bool aligned4 = ((p.y_ld | p.y_off) & 3) == 0 && (!has_res || ((p.r_ld | p.r_off) & 3) == 0);
+    if (p.out_mode != YOLO_OUT_HEAD && (p.Cout & 3) == 0 && aligned4) {
+        constexpr int OLD = BN + 4;
+        float* ost = As;                                   // [BM][OLD] floats <= 2 * (BM + BN) * LDS_LD
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + frow;
+            const bool nv = n < p.Cout;
+            const float sc = nv ? p.scale[n] : 0.f;
+            const float sh = nv ? p.shift[n] : 0.f;
+            float* dst = ost + wn * WN + j * 32 + frow;
+            YOLO_SWITCH_ACT(p.act,
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc + sh);
+                    })
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+#pragma unroll 4
+        for (int idx = tid; idx < BM * C4; idx += 256) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            if (m >= p.M || n >= p.Cout) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ost + row * OLD + c4 * 4);
+            if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.r_ld + p.r_off + n);
+            if (nan_chk && (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3])) saw_nan = true;
+            if (p.out_mode == YOLO_OUT_NHWC) {
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.y_ld + p.y_off + n) = v;
+            } else {                                        // YOLO_OUT_UPSAMPLE2X
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                const int W2 = 2 * p.Wo;
+                float* d = p.y + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + p.y_off + n;
+                *reinterpret_cast<f32x4*>(d) = v;
+                *reinterpret_cast<f32x4*>(d + p.y_ld) = v;
+                *reinterpret_cast<f32x4*>(d + (size_t)W2 * p.y_ld) = v;
+                *reinterpret_cast<f32x4*>(d + (size_t)(W2 + 1) * p.y_ld) = v;
+            }
+        }
+        if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + frow;
