@@ -972,3 +972,40 @@ def test_letterbox_vs_restatement(yt, h, w, size):
     np.testing.assert_array_equal(got[0].cpu().numpy(), want)
     boxes = [[0.5, 0.5, 0.2, 0.3, 0.9, 1.0], [0.1, 0.8, 0.05, 0.1, 0.7, 0.0]]
     assert yt.unletterbox_boxes(boxes, (h, w), (size, size)) == opre.unletterbox_boxes(boxes, (h, w), (size, size))
+
+
+@pytest.mark.parametrize("ac", [None, torch.bfloat16])
+def test_frozen_backbone_train_step(yt, ac):
+    """`freeze=True` (model.py:306-309): parameters of the first 9 top-level modules do not require grad. Their .grad
+    stays None, the trainable rest gets exactly the gradients of the unfrozen step (the backward simply stops at the
+    first trainable block), in fp32 and under bf16 autocast."""
+    nc, S, B = 2, 96, 2
+    anchors = gi.TRAIN_CASE["anchors"]
+    sd = onet.synth_state_dict(81, 3, nc, gain=gi.NET_GAIN)
+    x = onet.synth_input(82, B, S).cuda()
+    tg = [torch.from_numpy(t).cuda() for t in gi.synth_targets(B, S, nc, anchors, 83)]
+    sa = (torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)).cuda()
+    lf = yt.FusedYOLOLoss()
+    grads = []
+    for frozen in (False, True):
+        m = yt.YOLOv3(num_classes=nc, activation="mish")
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        if frozen:
+            for layer in list(m.layers)[:9]:
+                for p in layer.parameters():
+                    p.requires_grad_(False)
+        with torch.autocast("cuda", dtype=ac or torch.bfloat16, enabled=ac is not None):
+            po = m(x)
+        sum(sum(lf(po[i], tg[i], sa[i])) for i in range(3)).backward()
+        grads.append({k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()})
+    full, part = grads
+    n_frozen = 0
+    for k, g in part.items():
+        idx = int(k.split(".")[1])
+        if idx < 9:
+            assert g is None, k
+            n_frozen += 1
+        else:
+            assert g is not None and torch.equal(g, full[k]), k
+    assert n_frozen > 50

@@ -13,19 +13,23 @@ ap.add_argument("--classes", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
 ap.add_argument("--fused-loss", action="store_true", help="FusedYOLOLoss (3 HIP kernels per scale) instead of the PyTorch loss")
+ap.add_argument("--freeze", type=int, default=0, help="freeze the parameters of the first N top-level modules (freeze=True backbone)")
 ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 from bench import seeded_model
 m = seeded_model(yt, a.classes, dev).train()
 m._engine.compute_dtype = a.dtype
+for layer in list(m.layers)[:a.freeze]:
+    for p in layer.parameters():
+        p.requires_grad_(False)
 anchors = gi.TRAIN_CASE["anchors"]
 grids = [a.size // 32, a.size // 16, a.size // 8]
 sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(dev)
 x = torch.rand(a.batch, 3, a.size, a.size, device=dev)
 tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(a.batch, a.size, a.classes, anchors, 3)]
 lf = yt.FusedYOLOLoss() if (a.fused_loss or a.graph) else yt.YOLOLoss()
-opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
 
 def step(timing=None):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -50,7 +54,7 @@ if a.graph:
     # whole-step capture: forward(train) + loss + backward + SGD as ONE graph launch (no per-kernel launch cost).
     # Needs the per-forward NaN guard's host sync off and capturable optimizer state.
     m._engine.nan_check = False
-    opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -240,7 +240,16 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             t = dz_scratch[numel] = torch.empty(numel, dtype=plan.tdtype, device=dev)
         return t
 
-    for i in range(len(prog.ops) - 1, -1, -1):
+    # Frozen backbone (`freeze=True`, model.py:306-309,330-334): nothing below the first block that owns a trainable
+    # parameter needs a gradient, so the backward stops there (ops are in topological order: every producer of a block's
+    # input has a smaller index) and that block itself skips its input gradient.
+    def _trainable(op):
+        blk = op["block"]
+        ps = [blk.conv.weight] + ([blk.batch_norm.weight, blk.batch_norm.bias] if blk.batch_norm_act else [blk.conv.bias])
+        return any(need.get(id(q), False) for q in ps)
+    first_needed = 0 if want_input_grad else next((j for j, o in enumerate(prog.ops) if _trainable(o)), len(prog.ops))
+
+    for i in range(len(prog.ops) - 1, first_needed - 1, -1):
         op = prog.ops[i]
         blk, cv = op["block"], op["block"].conv
         xv, yv, rv = op["x"], op["y"], op["res"]
@@ -299,7 +308,8 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             grads[id(cv.weight)] = dw
             done(cv.weight)
         # ---------------------------------------------------------------- dgrad into the input's gradient
-        if xv.buf != prog.input.buf or want_input_grad:  # the image itself needs no gradient (train.py never asks)
+        if (xv.buf != prog.input.buf or want_input_grad) and i > first_needed - (1 if want_input_grad else 0):
+            # (the image itself needs no gradient — train.py never asks — and neither does anything under a frozen prefix)
             w = cv.weight.detach()
             flip = 1 if s == 1 else 0
             wp = plan.dgrad_w.get(i)
