@@ -254,8 +254,8 @@ int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_pack
     a.tiles_per_class = ceil_div(a.Mc, 64);
     a.tiles_n = ceil_div(cin, 64);
     a.Kpad = kpad_of(cout, 3);
-    YOLO_DISPATCH_DTYPE(dtype, "dgrad_s2",
-        hipLaunchKernelGGL(dgrad_s2_f32_kernel<T>, dim3(4 * a.tiles_per_class * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a));
+    if (dtype != YOLO_F32) return fail(YOLO_ERR_ARG, "dgrad_s2: unknown dtype %d", dtype);
+    hipLaunchKernelGGL(dgrad_s2_f32_kernel<float>, dim3(4 * a.tiles_per_class * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("dgrad_s2_f32");
 }
 
