@@ -1009,3 +1009,50 @@ def test_frozen_backbone_train_step(yt, ac):
         else:
             assert g is not None and torch.equal(g, full[k]), k
     assert n_frozen > 50
+
+
+@pytest.mark.parametrize("loss_name", ["YOLOLoss", "FusedYOLOLoss"])
+def test_reference_training_loop_runs_unchanged(yt, loss_name):
+    """The body of train_one_epoch (train.py:41-82) verbatim on this package's drop-in classes: default CUDA autocast
+    (fp16 kernels), loss inside the autocast block, GradScaler scale / step / update, LinearLR warm-up, and a change of
+    input size in the middle (train.py:45-46). The loss must stay finite, the scaler must take real steps and the
+    weights must move."""
+    nc = 2
+    anchors = gi.TRAIN_CASE["anchors"]
+    sd = onet.synth_state_dict(91, 3, nc, gain=gi.NET_GAIN)
+    model = yt.YOLOv3(num_classes=nc)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    optimizer = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    warmup_scheduler = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=0.1, total_iters=4)
+    loss_fn = getattr(yt, loss_name)()
+    grad_scaler = torch.amp.GradScaler()
+    w_before = model.layers[0].conv.weight.detach().clone()
+    losses = []
+    for batch_idx, S in enumerate([96, 96, 128, 128]):
+        grids = [S // 32, S // 16, S // 8]
+        scaled_anchors = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).cuda()
+        x = onet.synth_input(100 + batch_idx, 2, S)
+        y = [torch.from_numpy(t) for t in gi.synth_targets(2, S, nc, anchors, 110 + batch_idx)]
+        optimizer.zero_grad()
+        x = x.to("cuda")
+        y0, y1, y2 = (y[0].to("cuda"), y[1].to("cuda"), y[2].to("cuda"))
+        with torch.amp.autocast(device_type="cuda"):
+            out = model(x)
+            box_loss_0, obj_loss_0, no_obj_loss_0, class_loss_0 = loss_fn(out[0], y0, scaled_anchors[0])
+            box_loss_1, obj_loss_1, no_obj_loss_1, class_loss_1 = loss_fn(out[1], y1, scaled_anchors[1])
+            box_loss_2, obj_loss_2, no_obj_loss_2, class_loss_2 = loss_fn(out[2], y2, scaled_anchors[2])
+            box_loss = box_loss_0 + box_loss_1 + box_loss_2
+            obj_loss = obj_loss_0 + obj_loss_1 + obj_loss_2
+            no_obj_loss = no_obj_loss_0 + no_obj_loss_1 + no_obj_loss_2
+            class_loss = class_loss_0 + class_loss_1 + class_loss_2
+            loss = box_loss + obj_loss + no_obj_loss + class_loss
+        grad_scaler.scale(loss).backward()
+        grad_scaler.step(optimizer)
+        grad_scaler.update()
+        warmup_scheduler.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(l) for l in losses), losses
+    assert not torch.equal(model.layers[0].conv.weight.detach(), w_before)
+    assert grad_scaler.get_scale() >= 65536.0 / 4          # at most a couple of skipped (overflow) steps
+    assert all(torch.isfinite(p).all() for p in model.parameters())
