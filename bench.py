@@ -419,11 +419,11 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),
-            # HBM bytes of one launch of the dominant kernel (128->256 at 52x52, batch 32) from the PMC passes committed as
-            # profiles/r01/pmc_hbm_traffic.txt (separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 per the gfx950
-            # note of MI355X_MICROARCH.md): 82.8 MB read + 84.5 MB written vs 134.1 MB algorithmic (in + weights + out)
-            "traffic": 167.3e6 if (args.dtype == "fp32" and args.batch == 32 and args.size == 416) else None,
-            "traffic_unit": "HBM bytes per launch (PMC, conv_patch_f32<3,128> 128->256 @52x52); algorithmic 134.1e6",
+            # HBM bytes of one launch of the dominant kernel (conv_patch_f32<3,64>, 128->256 at 52x52, batch 32) from the PMC passes
+            # committed as profiles/r01/pmc_hbm_traffic.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE x2 per the
+            # gfx950 note of MI355X_MICROARCH.md): 58.2 MB read + 88.6 MB written vs 134.1 MB algorithmic (in + weights + out)
+            "traffic": 146.8e6 if (args.dtype == "fp32" and args.batch == 32 and args.size == 416) else None,
+            "traffic_unit": "HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6",
             "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
                        else f"conv_patch_h16 (3x3 launches, v_mfma_f32_32x32x16_{'f16' if args.dtype == 'fp16' else 'bf16'})"),
             "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
