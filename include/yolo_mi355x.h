@@ -220,6 +220,10 @@ int yolo_loss_bwd(const float* pred, const int64_t* strides5, const float* targe
  * buffer in the reference's concatenation order, demo.py:44-51). is_pred == 0: 5+nc must be 6. */
 int yolo_decode(void* pred, const int64_t* strides5, const float* anchors_3x2, int b, int g, int nc,
                 int is_pred, float* boxes, int n_total, int box_offset, void* stream);
+/* The three scales of one forward (is_pred = 1) in one launch: preds3[k] / strides15[5k..5k+4] / anchors3[k] / grids3[k] in the
+ * reference's concatenation order (scale 0, 1, 2: demo.py:44-51); boxes (B, n_total, 6) with n_total = sum 3 g_k^2. */
+int yolo_decode3(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
+                 float* boxes, int n_total, void* stream);
 
 /* Replaces non_max_suppression (utils.py:150-191) with calc_iou (utils.py:38-84) inlined,
  * batched over images. boxes: (B, n, 6) fp32. keep_idx: (B, n) int32, keep_count: (B) int32:

@@ -32,13 +32,13 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 // permuted view (element stride 1 along col) is read coalesced. For this library's contiguous
 // head layout (stride 1 along k) the 64 cells of a wave are first staged through LDS so global
 // reads are full lines.
-__global__ void decode_kernel(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
-                              const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
-                              float* __restrict__ boxes, int n_total, int box_offset) {
+__device__ __forceinline__ void decode_block(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
+                                             const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
+                                             float* __restrict__ boxes, int n_total, int box_offset, long long blk) {
     extern __shared__ __attribute__((aligned(16))) float tile[];           // [64][D] when sk == 1 && cells contiguous, else unused
     const int D = 5 + nc;
     const long long cells = (long long)B * 3 * g * g;
-    const long long cell0 = (long long)blockIdx.x * 64;
+    const long long cell0 = blk * 64;
     const long long cell = cell0 + threadIdx.x;
     const bool contiguous = (sk == 1 && sx == D && sy == (long long)g * D && sa == (long long)g * g * D &&
                              sb == 3LL * g * g * D);
@@ -99,6 +99,24 @@ __global__ void decode_kernel(float* __restrict__ pred, long long sb, long long 
     o[3] = inv * p3;
     o[4] = p4;
     o[5] = cls;
+}
+
+__global__ void decode_kernel(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
+                              const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
+                              float* __restrict__ boxes, int n_total, int box_offset) {
+    decode_block(pred, sb, sa, sy, sx, sk, anchors, B, g, nc, is_pred, boxes, n_total, box_offset, blockIdx.x);
+}
+
+// the three scales of one forward in ONE launch (demo.py:44-51 / utils.py:300-309 order): at batch 32 the three separate
+// launches were launch-latency-bound (3 x ~25 us for 129 MB)
+struct DecodeScale { float* pred; long long sb, sa, sy, sx, sk; const float* anchors; int g, box_offset; long long first_block; };
+struct Decode3Args { DecodeScale sc[3]; int B, nc, n_total; float* boxes; };
+
+__global__ void decode3_kernel(const Decode3Args a) {
+    const int k = (long long)blockIdx.x >= a.sc[2].first_block ? 2 : ((long long)blockIdx.x >= a.sc[1].first_block ? 1 : 0);
+    const DecodeScale& d = a.sc[k];
+    decode_block(d.pred, d.sb, d.sa, d.sy, d.sx, d.sk, d.anchors, a.B, d.g, a.nc, 1, a.boxes, a.n_total, d.box_offset,
+                 (long long)blockIdx.x - d.first_block);
 }
 
 // --------------------------------------------------------------------------------- NMS
@@ -294,6 +312,30 @@ int yolo_decode(void* pred, const int64_t* s, const float* anchors, int b, int g
                        (long long)s[0], (long long)s[1], (long long)s[2], (long long)s[3], (long long)s[4], anchors, b, g, nc,
                        is_pred, boxes, n_total, box_offset);
     return check_launch("decode");
+}
+
+int yolo_decode3(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
+                 float* boxes, int n_total, void* stream) {
+    if (!preds3 || !strides15 || !anchors3 || !grids3 || !boxes || b <= 0 || nc < 1) return fail(YOLO_ERR_ARG, "decode3: bad arguments");
+    Decode3Args a;
+    a.B = b; a.nc = nc; a.n_total = n_total; a.boxes = boxes;
+    long long blocks = 0;
+    int off = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int g = grids3[k];
+        if (!preds3[k] || !anchors3[k] || g <= 0) return fail(YOLO_ERR_ARG, "decode3: bad scale %d", k);
+        DecodeScale& d = a.sc[k];
+        d.pred = (float*)preds3[k]; d.anchors = anchors3[k]; d.g = g; d.box_offset = off; d.first_block = blocks;
+        d.sb = strides15[5 * k]; d.sa = strides15[5 * k + 1]; d.sy = strides15[5 * k + 2]; d.sx = strides15[5 * k + 3]; d.sk = strides15[5 * k + 4];
+        off += 3 * g * g;
+        blocks += ((long long)b * 3 * g * g + 63) / 64;
+    }
+    if (off != n_total) return fail(YOLO_ERR_ARG, "decode3: n_total %d != sum of 3 g^2 = %d", n_total, off);
+    if (blocks > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "decode3: too many cells");
+    const size_t lds = (size_t)64 * (5 + nc) * sizeof(float);
+    if (lds > 64 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "decode: %d classes exceed the staging tile", nc);
+    hipLaunchKernelGGL(decode3_kernel, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, a);
+    return check_launch("decode3");
 }
 
 size_t yolo_nms_workspace_bytes(int b, int n) {

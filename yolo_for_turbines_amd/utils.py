@@ -141,11 +141,23 @@ def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, b
     B = predictions[0].shape[0]
     n_per = [3 * p.shape[2] * p.shape[2] for p in predictions]
     total = sum(n_per)
-    boxes = torch.empty((B, total, 6), dtype=torch.float32, device=predictions[0].device)
-    off = 0
-    for p, a, n in zip(predictions, scaled_anchors, n_per):
-        decode_boxes(p, a, p.shape[2], True, out=boxes, box_offset=off)
-        off += n
+    dev = predictions[0].device
+    boxes = torch.empty((B, total, 6), dtype=torch.float32, device=dev)
+    if len(predictions) == 3 and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 5 for p in predictions) \
+            and len({p.shape[4] for p in predictions}) == 1:
+        with torch.cuda.device(dev):                      # the three scales in one launch
+            anc = [torch.as_tensor(a, dtype=torch.float32).reshape(3, 2).to(dev).contiguous() for a in scaled_anchors]
+            pp = (C.c_void_p * 3)(*[p.data_ptr() for p in predictions])
+            st = (C.c_int64 * 15)(*[v for p in predictions for v in p.stride()])
+            ap = (C.c_void_p * 3)(*[a.data_ptr() for a in anc])
+            gg = (C.c_int * 3)(*[p.shape[2] for p in predictions])
+            L.check(L.lib().yolo_decode3(pp, st, ap, gg, B, predictions[0].shape[4] - 5, boxes.data_ptr(), total, L.current_stream()),
+                    "yolo_decode3")
+    else:
+        off = 0
+        for p, a, n in zip(predictions, scaled_anchors, n_per):
+            decode_boxes(p, a, p.shape[2], True, out=boxes, box_offset=off)
+            off += n
     keep, count = nms_indices(boxes, iou_threshold, obj_threshold, box_format)
     return boxes, keep, count
 
