@@ -15,6 +15,10 @@
 //      fully contiguous 1 KiB global_load_dwordx4 wave-instruction, prefetched one K step (64 MFMAs)
 //      ahead into a second register set. Weights are L2/MALL resident (<= 18.9 MB per layer).
 //  MFMA             v_mfma_f32_32x32x2_f32, wave tile 64 x (BN/2), 2x2 waves, block 128 x BN.
+//  Occupancy        BN = 128: two patch buffers (64.5 KB LDS, 224 registers) -> 2 blocks per CU. BN = 64 can run with ONE
+//      patch buffer (36.9 KB, 148 registers, one more barrier per chunk) -> 3 blocks per CU, which covers prologue /
+//      epilogue better and fills 768 slots in one round at 13x13: the configuration measured fastest at 208 / 104 / 52 /
+//      13 (conv_f32.hip:pick_tile).
 #include "common.h"
 #include <cstdlib>
 
@@ -463,7 +467,7 @@ static int launch_v2(Conv2Args& a, hipStream_t s) {
     a.tiles_n = ceil_div(a.Cout, BN);
     const int tiles_r = ceil_div(a.rows_total, a.TH);
     a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
-    // resident blocks per CU (2 with these register/LDS footprints) x 256 CUs are dispatched at once
+    // resident blocks per CU (2, or 3 with a single patch buffer) x 256 CUs are dispatched at once
     a.first_wave = (a.bufmask ? 2 : 3) * 256;
     const long mfma_cycles = (long)a.KT * 32 * (BN / 64) * 64;  // one block's matrix work per wave
     a.stagger = g_v2_stagger ? (int)((mfma_cycles + 64 * 127 / 2) / (64 * 127)) : 0;
