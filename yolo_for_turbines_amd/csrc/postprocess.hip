@@ -186,6 +186,9 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const SBox* __restrict__ s
     unsigned long long word = 0;
     for (int jj = 0; jj < lim; ++jj) {
         const SBox o = cols[jj];
+        // a box of another class never suppresses (utils.py:183-186: kept if `cls != top.cls` OR iou < thr): skip the IoU
+        // when no row of this wave shares column jj's class — with 80 classes that is ~45 % of the columns
+        if (__ballot(o.cls == me.cls) == 0ull) continue;
         const float xa = max_nan(me.x1, o.x1), ya = max_nan(me.y1, o.y1);
         const float xb = min_nan(me.x2, o.x2), yb = min_nan(me.y2, o.y2);
         float iw = xb - xa, ih = yb - ya;
