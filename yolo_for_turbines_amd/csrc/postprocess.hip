@@ -227,11 +227,27 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
     int* out = keep_idx + (size_t)b * n;
     int count = 0;                                      // meaningful in wave 0 only
     const int nblk = (nv + 63) / 64;
+    // the row block's diagonal words, row_any word and original indices are fetched ONE block ahead: the loop is a serial
+    // chain of ~160 iterations per image, and a dependent global load per iteration was most of each iteration
+    unsigned long long d_next = 0ull, any_next = 0ull;
+    int ord_next = 0;
+    if (tid < 64 && nblk > 0) {
+        d_next = tid < nv ? mk[(size_t)tid * W] : 0ull;
+        any_next = any[0];
+        ord_next = tid < nv ? ord[tid] : 0;
+    }
     for (int rb = 0; rb < nblk; ++rb) {
         const int rows = nv - rb * 64 < 64 ? nv - rb * 64 : 64;
         if (tid < 64) {
             const int i = rb * 64 + tid;
-            const unsigned long long d = tid < rows ? mk[(size_t)i * W + rb] : 0ull;
+            const unsigned long long d = d_next, any_rb = any_next;
+            const int ord_i = ord_next;
+            if (rb + 1 < nblk) {
+                const int in = i + 64;
+                d_next = in < nv ? mk[(size_t)in * W + rb + 1] : 0ull;
+                any_next = any[rb + 1];
+                ord_next = in < nv ? ord[in] : 0;
+            }
             unsigned long long rem = removed[rb];
             const unsigned long long rowmask = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
             unsigned long long kept;
@@ -251,12 +267,12 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
             }
             if (tid < rows && ((kept >> tid) & 1ull)) {
                 const int pos = count + __popcll(kept & ((1ull << tid) - 1ull));
-                out[pos] = ord[i];
+                out[pos] = ord_i;
             }
             count += __popcll(kept);
             if (tid == 0) {
                 removed[W] = kept;
-                removed[W + 1] = kept & any[rb];        // kept rows that suppress something in a later block
+                removed[W + 1] = kept & any_rb;         // kept rows that suppress something in a later block
             }
         }
         __syncthreads();
