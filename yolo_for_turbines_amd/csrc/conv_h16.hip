@@ -299,8 +299,24 @@ __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN
         for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(An + c.a_off[i] + s * 32);
 }
 
+template <typename T, int KS, int STRIDE, int BN, int MASK>
+__device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p);
+
 template <typename T, int KS, int STRIDE, int BN, int MASK = 0>
-__global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) {
+__global__ __launch_bounds__(256) void conv_patch_h16(const ConvHArgs p) { conv_patch_h16_body<T, KS, STRIDE, BN, MASK>(p); }
+
+// Register cap for the 64-wide variants. Measured with per-block stamps: a CU held THREE blocks of the 1x1 variant
+// (128 VGPRs + 32 AGPRs = 160) but never more than TWO of the 3x3 variant at 132 + 32 = 164, although the compiler's
+// occupancy estimate says 3 for both (and LDS allows 4: tools/lds_occ_probe.hip) — the hardware allocates registers in
+// coarser granules than the estimate assumes. With this attribute the compiler keeps the accumulators in VGPRs and lands at
+// 154 (3x3) / 108 (1x1) registers in total; worth 1-2 % on the 64-wide layers.
+template <typename T, int KS, int STRIDE, int MASK = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void conv_patch_h16_n64(const ConvHArgs p) {
+    conv_patch_h16_body<T, KS, STRIDE, 64, MASK>(p);
+}
+
+template <typename T, int KS, int STRIDE, int BN, int MASK>
+__device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     constexpr int TN = BN / 64;
     static_assert(MASK == 0 || (KS == 3 && STRIDE == 1), "tap subsets are defined on the 3x3 stride-1 window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -740,7 +756,8 @@ static int launch_h(ConvHArgs& a, hipStream_t s) {
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;      // one block's matrix cycles per wave
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;   // s_sleep 32 = 2048 cycles
     const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
-    hipLaunchKernelGGL((conv_patch_h16<T, KS, STRIDE, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
+    if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, KS, STRIDE>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_patch_h16<T, KS, STRIDE, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16");
 }
 
@@ -754,7 +771,8 @@ static int launch_cls(ConvHArgs& a, hipStream_t s) {
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
     const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
-    hipLaunchKernelGGL((conv_patch_h16<T, 3, 1, BN, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
+    if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, 3, 1, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_patch_h16<T, 3, 1, BN, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16 (dgrad s2 class)");
 }
 
@@ -795,7 +813,7 @@ int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, c
     a.H = ho; a.W = wo; a.rows_total = n * ho;
     pick_tile_h(ho, ho, wo, 3, 1, &a.TH, &a.TW, &prmax);
     a.PC = a.TW + 2;
-    a.patch_cap = round_up(prmax * a.PC, 64);
+    a.patch_cap = round_up(prmax * a.PC, 8);               // see conv_h16_launch: keep two patch buffers under 40 KB when possible
     if (a.patch_cap < 224) a.patch_cap = 224;
     if (a.patch_cap > H_PATCH_CAP) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2 (16-bit): patch too large");
     a.tiles_w = ceil_div(a.W, a.TW);
@@ -839,7 +857,11 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
         pick_tile_h(d->h, a.Ho, a.Wo, 3, d->stride, &a.TH, &a.TW, &prmax);
         a.PC = d->stride * (a.TW - 1) + 3;
     }
-    a.patch_cap = round_up(prmax * a.PC, 64);
+    // Not rounded up to the staging granularity of 64 pixels (the stores are guarded): measured with per-block stamps, a CU
+    // never held more than TWO of the 64-wide 3x3 blocks although registers and the occupancy API allow three — their
+    // 2 x 256 x 80 B = 41.5 KB of LDS did not pack three to a CU (consistent with allocations not straddling the two 80 KB
+    // halves of the 160 KB LDS: 2 x 41.5 KB > 80 KB), while the 36.4 KB 1x1 blocks did run three deep.
+    a.patch_cap = round_up(prmax * a.PC, 8);
     if (a.patch_cap < 224) a.patch_cap = 224;              // epilogue stages 128 x 68 fp32 in the patch region
     if (a.patch_cap > H_PATCH_CAP) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): patch too large");
     a.tiles_w = ceil_div(a.W, a.TW);
