@@ -259,6 +259,37 @@ def test_nms_full_size_properties(yt):
         assert int(c2) == k and np.array_equal(again[:k].cpu().numpy(), np.arange(k))
 
 
+def test_nms_class_sorted_path_awkward_classes(yt):
+    """n >= 2048 takes the class-sorted path: class values that are fractional, negative, huge, -0.0 vs 0.0 and NaN
+    (a NaN class never equals itself, so such a box never suppresses nor is suppressed), few and many classes, ragged
+    numbers of valid boxes per image (including none and a single one) - exact indices against the C oracle."""
+    rng = np.random.Generator(np.random.PCG64(777))
+    palette = np.array([0.0, -0.0, 1.0, 2.0, 2.5, 0.5, -1.0, -3.0, 1e9, 4093.0, 4094.0, 4095.0, 5000.0, np.nan, 79.0, 3.0], F32)
+    imgs = []
+    for b in range(6):
+        n = 3000
+        bx = gi.boxes_clustered(n, 4, 600 + b, n_gt=12, jitter=0.2)
+        if b < 4:
+            bx[:, 5] = palette[rng.integers(0, len(palette), n)]
+        elif b == 4:
+            bx[:, 5] = 7.0                                   # one class: the dense O(n^2) case
+        bx[:, 4] = rng.random(n).astype(F32)
+        imgs.append(bx)
+    imgs[1][:, 4] *= 0.2                                     # nothing above 0.25 -> no valid boxes
+    imgs[2][:, 4] *= 0.2
+    imgs[2][1234, 4] = 0.9                                   # exactly one valid box
+    imgs[3][::3, 4] = 0.75                                   # many equal scores: index order breaks ties
+    batch = np.stack(imgs)
+    keep, count = yt.nms_indices(torch.from_numpy(batch).cuda(), 0.4, 0.25, "center")
+    for b in range(6):
+        want = opp.nms_indices_c(batch[b], 0.4, 0.25, "center")
+        assert int(count[b]) == len(want)
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+    assert int(count[1]) == 0 and int(count[2]) == 1
+    keep, count = yt.nms_indices(torch.from_numpy(batch[0]).cuda(), 0.0, -1.0, "corner")     # thr 0: everything overlaps
+    np.testing.assert_array_equal(keep[:int(count)].cpu().numpy(), opp.nms_indices_c(batch[0], 0.0, -1.0, "corner"))
+
+
 def test_detect_pipeline_vs_oracle(yt):
     """forward -> decode (3 scales, reference concatenation order) -> NMS, against the oracle's
     decode of the oracle's forward; thresholds chosen so a few hundred boxes survive."""

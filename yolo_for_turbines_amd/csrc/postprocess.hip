@@ -173,30 +173,33 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
 // image); the keys are unique for valid boxes (the index is part of the key), so sorting them gives the identical
 // order: rocPRIM's device radix sort (the plain library piece of this file) + a key builder and a gather.
 // (rocPRIM's SEGMENTED sort was tried first: with 16 segments of 10,000 keys it was slower than the counting rank.)
+// A key is "valid" iff its score field is not all ones (only a NaN score could map there, and NaN is filtered), so the
+// kernels after the sort read validity off the key and the one thread at the valid/filtered boundary of an image writes
+// nvalid[b] (zeroed before): no counting atomics (2,500 same-address atomics per call were most of this kernel's 30 us).
+__device__ __forceinline__ bool key_valid(unsigned long long k) { return ((k >> 20) & 0xffffffffull) != 0xffffffffull; }
+
 __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ boxes, int n, double obj_thr,
-                                                       unsigned long long* __restrict__ keys, int* __restrict__ nvalid) {
+                                                       unsigned long long* __restrict__ keys) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    bool valid = false;
-    if (i < n) {
-        const unsigned long long k = make_key(boxes[((size_t)b * n + i) * 6 + 4], i, obj_thr);
-        valid = k != ~0ull;
-        // image (12 bits) | descending-score field (32 bits; all ones = filtered) | index (20 bits): ONE radix sort of the
-        // whole batch leaves image b's boxes in [b n, (b + 1) n), valid ones first, in the reference's stable order
-        const unsigned long long sc = valid ? (k >> 32) : 0xffffffffull;
-        keys[(size_t)b * n + i] = ((unsigned long long)b << 52) | (sc << 20) | (unsigned long long)i;
-    }
-    const unsigned long long bal = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(nvalid + b, __popcll(bal));
+    if (i >= n) return;
+    const unsigned long long k = make_key(boxes[((size_t)b * n + i) * 6 + 4], i, obj_thr);
+    // image (12 bits) | descending-score field (32 bits; all ones = filtered) | index (20 bits): ONE radix sort of the
+    // whole batch leaves image b's boxes in [b n, (b + 1) n), valid ones first, in the reference's stable order
+    const unsigned long long sc = k != ~0ull ? (k >> 32) : 0xffffffffull;
+    keys[(size_t)b * n + i] = ((unsigned long long)b << 52) | (sc << 20) | (unsigned long long)i;
 }
 
 __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ boxes, const unsigned long long* __restrict__ sorted,
-                                                         const int* __restrict__ nvalid, int n, int center, int* __restrict__ order,
+                                                         int* __restrict__ nvalid, int n, int center, int* __restrict__ order,
                                                          SBox* __restrict__ sbox) {
     const int b = blockIdx.y;
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= nvalid[b]) return;
-    const int i = (int)(unsigned)(sorted[(size_t)b * n + r] & 0xfffffull);
+    if (r >= n) return;
+    const unsigned long long key = sorted[(size_t)b * n + r];
+    if (!key_valid(key)) return;
+    if (r == n - 1 || !key_valid(sorted[(size_t)b * n + r + 1])) nvalid[b] = r + 1;
+    const int i = (int)(unsigned)(key & 0xfffffull);
     const float* s = boxes + ((size_t)b * n + i) * 6;
     float x = s[0], y = s[1];
     const float w = s[2], h = s[3];
@@ -205,6 +208,145 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict
     o.x1 = x; o.y1 = y; o.x2 = x + w; o.y2 = y + h; o.area = w * h; o.cls = s[5]; o.w = w; o.h = h;
     sbox[(size_t)b * n + r] = o;
     order[(size_t)b * n + r] = i;
+}
+
+// ---- class-sorted variant (large n) ---------------------------------------------------------------------------------
+// A box only ever suppresses boxes of its own class (utils.py:183-186), so after a second STABLE sort by class the
+// suppression matrix is block diagonal: the mask kernel visits only the column blocks whose class range overlaps the row
+// block's (1/nc of the pairs for nc balanced classes) and the scan ORs only those. Greedy NMS per class in score order
+// is exactly the reference's result; the kept set is then emitted in the reference's (global score) order by a slot
+// array indexed with the global rank + an ordered compaction.
+__device__ __forceinline__ unsigned class_bucket(float c) {   // equal float classes -> equal bucket; ascending-sortable
+    return (c >= 0.0f && c < 4094.0f && c == floorf(c)) ? (unsigned)c : 4094u;
+}
+
+// key2 = image (11 bits, top bit clear) | class bucket (12; 0xfff = filtered) | global rank (20) | original index (20), sorted
+// on bits 40..62. (end_bit must stay below 64 with begin_bit > 0: rocPRIM's merge path builds its mask as
+// (1 << (begin + bits)) - 1, which is undefined for 64 and sorted on the LOW bits instead when tried.)
+__global__ __launch_bounds__(256) void nms_keys2_kernel(const float* __restrict__ boxes, const unsigned long long* __restrict__ sorted,
+                                                        int* __restrict__ nvalid, int n, unsigned long long* __restrict__ keys2) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const unsigned long long key = sorted[(size_t)b * n + r];
+    const unsigned long long i = key & 0xfffffull;
+    unsigned long long c = 0xfffull;
+    if (key_valid(key)) {
+        c = class_bucket(boxes[((size_t)b * n + i) * 6 + 5]);
+        if (r == n - 1 || !key_valid(sorted[(size_t)b * n + r + 1])) nvalid[b] = r + 1;
+    }
+    keys2[(size_t)b * n + r] = ((unsigned long long)b << 52) | (c << 40) | ((unsigned long long)r << 20) | i;
+}
+
+__global__ __launch_bounds__(256) void nms_gather2_kernel(const float* __restrict__ boxes, const unsigned long long* __restrict__ sorted2,
+                                                          const int* __restrict__ nvalid, int n, int W, int center,
+                                                          int* __restrict__ order, int* __restrict__ grank, SBox* __restrict__ sbox,
+                                                          int* __restrict__ blk_lo, int* __restrict__ blk_hi) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int nv = nvalid[b];
+    if (q >= nv) return;
+    const unsigned long long k = sorted2[(size_t)b * n + q];
+    const int i = (int)(unsigned)(k & 0xfffffull);
+    const float* s = boxes + ((size_t)b * n + i) * 6;
+    float x = s[0], y = s[1];
+    const float w = s[2], h = s[3];
+    if (center) { x = x - w / 2.0f; y = y - h / 2.0f; }            // utils.py:60-64
+    SBox o;
+    o.x1 = x; o.y1 = y; o.x2 = x + w; o.y2 = y + h; o.area = w * h; o.cls = s[5]; o.w = w; o.h = h;
+    sbox[(size_t)b * n + q] = o;
+    order[(size_t)b * n + q] = i;
+    grank[(size_t)b * n + q] = (int)(unsigned)((k >> 20) & 0xfffffull);
+    const int c = (int)(unsigned)((k >> 40) & 0xfffull);
+    if ((q & 63) == 0) blk_lo[(size_t)b * W + (q >> 6)] = c;
+    if ((q & 63) == 63 || q == nv - 1) blk_hi[(size_t)b * W + (q >> 6)] = c;
+}
+
+// grid (S, W, B), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
+__global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
+                                                             const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
+                                                             int W, float thr, unsigned long long* __restrict__ mask,
+                                                             unsigned long long* __restrict__ row_any) {
+    const int rb = blockIdx.y, b = blockIdx.z;
+    const int nv = nvalid[b];
+    if (rb * 64 >= nv) return;
+    const int nblk = (nv + 63) / 64;
+    __shared__ SBox cols[64];
+    const SBox* sb = sbox + (size_t)b * n;
+    const int i = rb * 64 + threadIdx.x;
+    const bool active = i < nv;
+    const SBox me = sb[active ? i : nv - 1];
+    const int hi_r = blk_hi[(size_t)b * W + rb];
+    for (int cb = rb + blockIdx.x; cb < nblk; cb += gridDim.x) {
+        if (blk_lo[(size_t)b * W + cb] > hi_r) break;    // classes ascend: no later block can match either
+        const int j = cb * 64 + threadIdx.x;
+        __syncthreads();
+        if (j < nv) cols[threadIdx.x] = sb[j];
+        __syncthreads();
+        const int lim = nv - cb * 64 < 64 ? nv - cb * 64 : 64;
+        unsigned long long word = 0;
+        for (int jj = 0; jj < lim; ++jj) {
+            const SBox o = cols[jj];
+            if (__ballot(active && o.cls == me.cls) == 0ull) continue;
+            const float xa = max_nan(me.x1, o.x1), ya = max_nan(me.y1, o.y1);
+            const float xb = min_nan(me.x2, o.x2), yb = min_nan(me.y2, o.y2);
+            float iw = xb - xa, ih = yb - ya;
+            iw = iw < 0.f ? 0.f : iw;
+            ih = ih < 0.f ? 0.f : ih;
+            const float inter = iw * ih;
+            const float uni = (me.area + o.area) - inter;
+            const float iou = inter / (uni + 1e-6f);
+            const bool survive = (o.cls != me.cls) || (iou < thr);
+            if (!survive && cb * 64 + jj > i) word |= 1ull << jj;
+        }
+        if (active) mask[((size_t)b * n + i) * W + cb] = word;
+        const unsigned long long bal = __ballot(active && word != 0ull);
+        if (cb > rb && threadIdx.x == 0 && bal) atomicOr(&row_any[(size_t)b * W + rb], bal);
+    }
+}
+
+// kept rows (bit q%64 of keptw[q/64]) go to slot[global rank]; done here, in parallel, because 64 scattered stores per
+// scan iteration had to drain before each of its barriers (the scan took 450 us that way, 2.5x the unsorted one)
+__global__ __launch_bounds__(256) void nms_place_kernel(const unsigned long long* __restrict__ keptw, const int* __restrict__ order,
+                                                        const int* __restrict__ grank, const int* __restrict__ nvalid, int n, int W,
+                                                        int* __restrict__ slot) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nvalid[b]) return;
+    if ((keptw[(size_t)b * W + (q >> 6)] >> (q & 63)) & 1ull) slot[(size_t)b * n + grank[(size_t)b * n + q]] = order[(size_t)b * n + q];
+}
+
+// kept boxes were written to slot[global rank] (-1 elsewhere): ordered compaction = the reference's output order
+__global__ __launch_bounds__(256) void nms_compact_kernel(const int* __restrict__ slot, const int* __restrict__ nvalid, int n,
+                                                          int* __restrict__ keep_idx) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nv = nvalid[b];
+    const int* sl = slot + (size_t)b * n;
+    int* out = keep_idx + (size_t)b * n;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
+    for (int g0 = 0; g0 < nv; g0 += 1024) {              // thread: 4 consecutive ranks per round
+        const int g = g0 + tid * 4;
+        int v[4];
+        int before = 0, wave_total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = g + k < nv ? sl[g + k] : -1;
+            const unsigned long long bal = __ballot(v[k] >= 0);
+            before += __popcll(bal & lt);
+            wave_total += __popcll(bal);
+        }
+        __syncthreads();
+        if (lane == 0) wsum[wave] = wave_total;
+        __syncthreads();
+        int off = base + before;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (v[k] >= 0) out[off++] = v[k];
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
 }
 
 // grid (W, W, B), 64 threads. word (i, cb): bit jj set <=> j = cb*64+jj > i, same class, !(iou < thr)
@@ -295,16 +437,19 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
             if (__ballot(d != 0ull) == 0ull) {
                 kept = rowmask & ~rem;                  // nothing inside this block suppresses anything
             } else {
+                // only rows that HAVE a diagonal bit can change the outcome; visit those in order
                 const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-                kept = 0;
-                for (int t = 0; t < rows; ++t) {
+                unsigned long long cand = __ballot(d != 0ull);
+                while (cand) {
+                    const int t = __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
                     if (!((rem >> t) & 1ull)) {
-                        kept |= 1ull << t;
-                        const unsigned lo = __builtin_amdgcn_readlane(dlo, t);
-                        const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
-                        rem |= ((unsigned long long)hi << 32) | lo;
+                        const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                        const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                        rem |= ((unsigned long long)wh << 32) | wl;
                     }
                 }
+                kept = rowmask & ~rem;
             }
             if (tid < rows && ((kept >> tid) & 1ull)) {
                 const int pos = count + __popcll(kept & ((1ull << tid) - 1ull));
@@ -335,14 +480,118 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
     if (tid == 0) keep_count[b] = count;
 }
 
+// ---- scan for class-sorted rows: classes never interact, so the image's rows are cut at class boundaries into up to 16
+// ranges of about equal length and ONE WAVE runs the greedy pass over each range, with no workgroup barrier inside the
+// loop (the per-image chain of ~160 row blocks becomes ~10 per wave at 80 classes; with 2 classes two waves work).
+// A 64-row block that straddles a cut is visited by both neighbours, each with its own row mask. Kept rows are reported
+// as bits of keptw (atomicOr: straddling blocks) and placed in output order by nms_place_kernel.
+__global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned long long* __restrict__ mask,
+                                                               const unsigned long long* __restrict__ sorted2,
+                                                               const int* __restrict__ nvalid, const unsigned long long* __restrict__ row_any,
+                                                               const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n, int W,
+                                                               unsigned long long* __restrict__ keptw, int* __restrict__ keep_count) {
+    extern __shared__ unsigned long long lds[];         // [K][W] removed words per wave, then lo[W], hi[W] (int), the count, cuts
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, K = blockDim.x >> 6;
+    const int nv = nvalid[b];
+    const int nblk = (nv + 63) / 64;
+    unsigned long long* removed = lds + (size_t)wave * W;
+    int* lo = (int*)(lds + (size_t)K * W);
+    int* hi = lo + W;
+    int* total = hi + W;
+    for (int c = tid; c < K * W; c += blockDim.x) lds[c] = 0ull;
+    for (int c = tid; c < nblk; c += blockDim.x) { lo[c] = blk_lo[(size_t)b * W + c]; hi[c] = blk_hi[(size_t)b * W + c]; }
+    if (tid == 0) *total = 0;
+    __syncthreads();
+    // range of this wave: cuts at the first class boundary at or after k nv / K (upper bound of the bucket just before it)
+    const unsigned long long* keys = sorted2 + (size_t)b * n;
+    auto cut = [&](int k) -> int {
+        if (k <= 0) return 0;
+        if (k >= K) return nv;
+        const int target = (int)((long long)nv * k / K);
+        if (target <= 0) return 0;
+        const unsigned bucket = (unsigned)((keys[target - 1] >> 40) & 0xfffull);
+        int a = target, z = nv;                         // first q in [target, nv) with bucket(q) > bucket; buckets ascend
+        while (a < z) {
+            const int m = (a + z) >> 1;
+            if ((unsigned)((keys[m] >> 40) & 0xfffull) > bucket) z = m; else a = m + 1;
+        }
+        return a;
+    };
+    int* cuts = total + 1;                              // [K + 1], one binary search each, in parallel
+    if (tid <= K) cuts[tid] = cut(tid);
+    __syncthreads();
+    const int s0 = cuts[wave], s1 = cuts[wave + 1];
+    int count = 0;
+    if (s0 < s1) {
+        const unsigned long long* mk = mask + (size_t)b * n * W;
+        const unsigned long long* any = row_any + (size_t)b * W;
+        const int rb0 = s0 >> 6, rb1 = (s1 - 1) >> 6;
+        auto rows_of = [&](int rb) -> unsigned long long {   // rows of block rb inside [s0, s1)
+            const int a = s0 - rb * 64 > 0 ? s0 - rb * 64 : 0, z = s1 - rb * 64 < 64 ? s1 - rb * 64 : 64;
+            const unsigned long long upto = z == 64 ? ~0ull : ((1ull << z) - 1ull);
+            return upto & ~((1ull << a) - 1ull);
+        };
+        unsigned long long d_next = ((rows_of(rb0) >> lane) & 1ull) ? mk[(size_t)(rb0 * 64 + lane) * W + rb0] : 0ull;
+        unsigned long long any_next = any[rb0];
+        for (int rb = rb0; rb <= rb1; ++rb) {
+            const unsigned long long rowmask = rows_of(rb);
+            const unsigned long long d = d_next, any_rb = any_next;
+            if (rb < rb1) {
+                d_next = ((rows_of(rb + 1) >> lane) & 1ull) ? mk[(size_t)((rb + 1) * 64 + lane) * W + rb + 1] : 0ull;
+                any_next = any[rb + 1];
+            }
+            const unsigned long long rem_v = removed[rb];   // wave-uniform: keep the serial chain on the scalar unit
+            const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem_v);
+            const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem_v >> 32));
+            unsigned long long rem = ((unsigned long long)rem_hi << 32) | rem_lo;
+            unsigned long long cand = __ballot(d != 0ull);
+            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+            while (cand) {                              // only rows with a diagonal bit can change the outcome
+                const int t = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (!((rem >> t) & 1ull)) {
+                    const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                    const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                    rem |= ((unsigned long long)wh << 32) | wl;
+                }
+            }
+            const unsigned long long kept = rowmask & ~rem;
+            count += __popcll(kept);
+            if (lane == 0 && kept) atomicOr(&keptw[(size_t)b * W + rb], kept);
+            const unsigned long long work = kept & any_rb;  // kept rows with a bit in some later column block
+            if (work) {
+                const int hi_r = hi[rb];
+                for (int c = rb + 1 + lane; c <= rb1; c += 64) {
+                    if (lo[c] > hi_r) break;            // never written: classes above this row block's
+                    unsigned long long acc = 0ull, wk = work;
+                    while (wk) {
+                        const int t = __builtin_ctzll(wk);
+                        wk &= wk - 1ull;
+                        acc |= mk[(size_t)(rb * 64 + t) * W + c];
+                    }
+                    if (acc) removed[c] |= acc;         // this lane owns word c of this wave's array
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes before its next read
+        }
+    }
+    if (lane == 0 && count) atomicAdd(total, count);
+    __syncthreads();
+    if (tid == 0) keep_count[b] = *total;
+}
+
 struct NmsWs { int* nvalid; unsigned long long* row_any; int* order; SBox* sbox; unsigned long long* mask; size_t zero_bytes; size_t total;
-               unsigned long long* keys_in; unsigned long long* keys_out; void* sort_tmp; size_t sort_tmp_bytes; };
+               unsigned long long* keys_in; unsigned long long* keys_out; void* sort_tmp; size_t sort_tmp_bytes;
+               int* grank; int* blk_lo; int* blk_hi; unsigned long long* keptw; };
 
 static size_t sort_tmp_bytes(int b, int n) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)b * n, 0, 64,
                                    (hipStream_t)0);
-    return bytes;
+    size_t bytes2 = 0;
+    (void)rocprim::radix_sort_keys(nullptr, bytes2, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)b * n, 40, 63,
+                                   (hipStream_t)0);
+    return bytes > bytes2 ? bytes : bytes2;
 }
 
 static NmsWs carve(void* base, int b, int n) {
@@ -352,7 +601,8 @@ static NmsWs carve(void* base, int b, int n) {
     NmsWs w;
     w.nvalid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1));
     w.row_any = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
-    w.zero_bytes = off;                                 // nvalid + row_any are zeroed by one memset per call
+    w.keptw = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
+    w.zero_bytes = off;                                 // nvalid + row_any + keptw are zeroed by one memset per call
     w.order = (int*)take(sizeof(int) * (size_t)b * n);
     w.sbox = (SBox*)take(sizeof(SBox) * (size_t)b * n);
     w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)b * n * W);
@@ -360,6 +610,9 @@ static NmsWs carve(void* base, int b, int n) {
     w.keys_out = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)b * n);
     w.sort_tmp_bytes = (b > 0 && n > 0) ? sort_tmp_bytes(b, n) : 0;
     w.sort_tmp = take(w.sort_tmp_bytes ? w.sort_tmp_bytes : 8);
+    w.grank = (int*)take(sizeof(int) * (size_t)b * n);
+    w.blk_lo = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * W);
+    w.blk_hi = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * W);
     w.total = off;
     return w;
 }
@@ -431,22 +684,59 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
     if (b > 65535 || W > 65535) return fail(YOLO_ERR_UNSUPPORTED, "nms: grid too large");
     if (hipMemsetAsync(w.nvalid, 0, w.zero_bytes, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
     int rc;
-    if (n >= 2048 && n < (1 << 20) && b <= 4096) {        // large n: sort the keys instead of counting (same order, see above)
-        hipLaunchKernelGGL(nms_keys_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, boxes, n, obj_threshold, w.keys_in, w.nvalid);
+    const bool sorted_keys = n >= 2048 && n < (1 << 20) && b <= 2047;      // large n: sort the keys instead of counting
+    const size_t fixed = (size_t)W * 8 + 128;               // class-range scan: lo/hi, count, cuts ...
+    int K = (int)((60 * 1024 - (long long)fixed) / (long long)((size_t)W * 8));   // ... and one removed[] array per wave, in LDS
+    K = K > 16 ? 16 : K;
+    const dim3 gn(ceil_div(n, 256), b);
+    if (sorted_keys && K < 1) {                             // n > ~245,000: score order only, the plain mask and scan
+        hipLaunchKernelGGL(nms_keys_kernel, gn, dim3(256), 0, st, boxes, n, obj_threshold, w.keys_in);
         rc = check_launch("nms_keys");
         if (rc) return rc;
         size_t tb = w.sort_tmp_bytes;
         if (rocprim::radix_sort_keys(w.sort_tmp, tb, w.keys_in, w.keys_out, (size_t)b * n, 0, 64, st) != hipSuccess)
             return fail(YOLO_ERR_LAUNCH, "nms: radix sort");
-        hipLaunchKernelGGL(nms_gather_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, boxes, w.keys_out, w.nvalid, n, center, w.order,
-                           w.sbox);
+        hipLaunchKernelGGL(nms_gather_kernel, gn, dim3(256), 0, st, boxes, w.keys_out, w.nvalid, n, center, w.order, w.sbox);
         rc = check_launch("nms_gather");
+        if (rc) return rc;
+    } else if (sorted_keys) {                               // + class-sorted rows
+        hipLaunchKernelGGL(nms_keys_kernel, gn, dim3(256), 0, st, boxes, n, obj_threshold, w.keys_in);
+        rc = check_launch("nms_keys");
+        if (rc) return rc;
+        size_t tb = w.sort_tmp_bytes;
+        if (rocprim::radix_sort_keys(w.sort_tmp, tb, w.keys_in, w.keys_out, (size_t)b * n, 0, 64, st) != hipSuccess)
+            return fail(YOLO_ERR_LAUNCH, "nms: radix sort");
+        hipLaunchKernelGGL(nms_keys2_kernel, gn, dim3(256), 0, st, boxes, w.keys_out, w.nvalid, n, w.keys_in);
+        rc = check_launch("nms_keys2");
+        if (rc) return rc;
+        tb = w.sort_tmp_bytes;
+        if (rocprim::radix_sort_keys(w.sort_tmp, tb, w.keys_in, w.keys_out, (size_t)b * n, 40, 63, st) != hipSuccess)
+            return fail(YOLO_ERR_LAUNCH, "nms: radix sort (class)");
+        int* slot = (int*)w.keys_in;                        // free again: kept boxes by global rank, -1 elsewhere
+        if (hipMemsetAsync(slot, 0xff, sizeof(int) * (size_t)b * n, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
+        hipLaunchKernelGGL(nms_gather2_kernel, gn, dim3(256), 0, st, boxes, w.keys_out, w.nvalid, n, W, center, w.order, w.grank,
+                           w.sbox, w.blk_lo, w.blk_hi);
+        rc = check_launch("nms_gather2");
+        if (rc) return rc;
+        hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(W < 8 ? W : 8, W, b), dim3(64), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
+                           W, (float)iou_threshold, w.mask, w.row_any);
+        rc = check_launch("nms_mask_sorted");
+        if (rc) return rc;
+        const size_t lds = (size_t)K * W * 8 + fixed;
+        hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(b), dim3(64 * K), lds, st, w.mask, w.keys_out, w.nvalid, w.row_any, w.blk_lo,
+                           w.blk_hi, n, W, w.keptw, keep_count);
+        rc = check_launch("nms_scan_classes");
+        if (rc) return rc;
+        hipLaunchKernelGGL(nms_place_kernel, gn, dim3(256), 0, st, w.keptw, w.order, w.grank, w.nvalid, n, W, slot);
+        rc = check_launch("nms_place");
+        if (rc) return rc;
+        hipLaunchKernelGGL(nms_compact_kernel, dim3(b), dim3(256), 0, st, slot, w.nvalid, n, keep_idx);
+        return check_launch("nms_compact");
     } else {
-        hipLaunchKernelGGL(nms_rank_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, boxes, n, obj_threshold, center, w.order,
-                           w.sbox, w.nvalid);
+        hipLaunchKernelGGL(nms_rank_kernel, gn, dim3(256), 0, st, boxes, n, obj_threshold, center, w.order, w.sbox, w.nvalid);
         rc = check_launch("nms_rank");
+        if (rc) return rc;
     }
-    if (rc) return rc;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, b), dim3(64), 0, st, w.sbox, w.nvalid, n, W, (float)iou_threshold, w.mask, w.row_any);
     rc = check_launch("nms_mask");
     if (rc) return rc;
