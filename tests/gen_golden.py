@@ -363,8 +363,55 @@ def gen_targets():
     np.savez_compressed(os.path.join(OUT, "targets.npz"), **out)
 
 
+# ------------------------------------------------------------- checkpoint format
+def gen_checkpoint():
+    import yolo_for_turbines_amd as yt
+    out = {}
+    m, opt = gi.checkpoint_setup(ref_model.YOLOv3)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ref.pth.tar")
+        ref_utils.save_checkpoint(m, opt, filename=path)
+        ck = torch.load(path)
+        out["top_keys"] = np.array(list(ck.keys()))
+        out["param_names"] = np.array([k for k, _ in m.named_parameters()])
+        out["state_dict_keys"] = np.array(list(ck["state_dict"].keys()))
+        out["state_dict_sums"] = np.array([float(v.double().sum()) for v in ck["state_dict"].values()])
+        o = ck["optimizer"]
+        out["opt_top_keys"] = np.array(list(o.keys()))
+        out["opt_state_ids"] = np.array(list(o["state"].keys()), np.int64)
+        out["opt_state_entry_keys"] = np.array(sorted(o["state"][0].keys()))
+        out["momentum_sums"] = np.array([float(o["state"][i]["momentum_buffer"].double().sum()) for i in o["state"]])
+        g = o["param_groups"][0]
+        out["group_keys"] = np.array(sorted(g.keys()))
+        out["group_params"] = np.array(g["params"], np.int64)
+        out["group_scalars"] = np.array([g["lr"], g["momentum"], g["dampening"], g["weight_decay"]], np.float64)
+        # cross-load, here where both exist: the reference's file into this package's model + optimizer ...
+        m2 = yt.YOLOv3(num_classes=2)
+        opt2 = torch.optim.SGD(m2.parameters(), lr=0.5, momentum=0.9, weight_decay=5e-4)
+        yt.load_checkpoint(m2, opt2, lr=0.125, filename=path)
+        for (k, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert k == k2 and torch.equal(a, b), k
+        for i, (pa, pb) in enumerate(zip(m.parameters(), m2.parameters())):
+            assert torch.equal(opt.state[pa]["momentum_buffer"], opt2.state[pb]["momentum_buffer"]), i
+        assert all(gr["lr"] == 0.125 for gr in opt2.param_groups)
+        # ... and this package's file into the reference's (its loader prefixes config.MODEL_FOLDER)
+        mine = os.path.join(td, "mine.pth.tar")
+        yt.save_checkpoint(m2, opt2, filename=mine)
+        m3 = ref_model.YOLOv3(num_classes=2)
+        opt3 = torch.optim.SGD(m3.parameters(), lr=0.5, momentum=0.9, weight_decay=5e-4)
+        import config as ref_config
+        ref_config.MODEL_FOLDER = td
+        ref_utils.load_checkpoint(m3, opt3, lr=0.25, filename="mine.pth.tar")
+        for (k, a), (k3, c) in zip(m.state_dict().items(), m3.state_dict().items()):
+            assert k == k3 and torch.equal(a, c), k
+        for pa, pc in zip(m.parameters(), m3.parameters()):
+            assert torch.equal(opt.state[pa]["momentum_buffer"], opt3.state[pc]["momentum_buffer"])
+        out["cross_load_ok"] = np.array([1, 1], np.int64)       # [reference file -> this package, this package's file -> reference]
+    np.savez_compressed(os.path.join(OUT, "checkpoint.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat", "targets"]
+    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat", "targets", "checkpoint"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

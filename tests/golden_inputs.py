@@ -338,3 +338,19 @@ def eval_batches():
             preds.append(p)
         out.append((np.zeros((c["batch"], 3, S, S), F32), tg, preds))
     return out
+
+
+# ------------------------------------------------------------------ checkpoint format
+def checkpoint_setup(model_cls, nc=2):
+    """Deterministic model + SGD state shared by the generator (reference model) and the tests (this package's model):
+    synthetic weights, grad = 0.01 * param, one SGD step, so every parameter has a momentum buffer."""
+    import torch
+    from oracle import net as onet
+    sd = onet.synth_state_dict(31, 3, nc, gain=1.0)
+    m = model_cls(num_classes=nc)
+    m.load_state_dict(sd)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)     # train.py:171-172
+    for p in m.parameters():
+        p.grad = 0.01 * p.detach()
+    opt.step()
+    return m, opt

@@ -130,3 +130,40 @@ def test_cpu_tensor_and_missing_gpu_fail_loudly():
         yt.decode_boxes(torch.zeros(1, 3, 2, 2, 7), torch.ones(3, 2), 2)
     with pytest.raises(RuntimeError, match="MI355X only"):
         yt.nms_indices(torch.zeros(4, 6), 0.5, 0.5)
+
+
+def test_checkpoint_format_matches_reference(golden, tmp_path):
+    """save_checkpoint / load_checkpoint (utils.py:383-416): the file this package writes for a deterministic model +
+    SGD-momentum state has the reference's structure, key order, parameter order and per-tensor sums
+    (tests/golden/checkpoint.npz, written where the reference's own save_checkpoint ran; the generator also loaded each
+    side's file with the other side's loader). Round trip restores everything and forces the learning rate."""
+    import torch
+    import yolo_for_turbines_amd as yt
+    from tests import golden_inputs as gi
+    g = golden("checkpoint")
+    assert list(g["cross_load_ok"]) == [1, 1]
+    m, opt = gi.checkpoint_setup(yt.YOLOv3)
+    assert [k for k, _ in m.named_parameters()] == list(g["param_names"])
+    path = tmp_path / "ck.pth.tar"
+    yt.save_checkpoint(m, opt, filename=str(path))
+    ck = torch.load(str(path))
+    assert list(ck.keys()) == list(g["top_keys"])
+    assert list(ck["state_dict"].keys()) == list(g["state_dict_keys"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in ck["state_dict"].values()], g["state_dict_sums"], rtol=1e-12, atol=0)
+    o = ck["optimizer"]
+    assert list(o.keys()) == list(g["opt_top_keys"])
+    assert list(o["state"].keys()) == list(g["opt_state_ids"])
+    assert sorted(o["state"][0].keys()) == list(g["opt_state_entry_keys"])
+    np.testing.assert_allclose([float(o["state"][i]["momentum_buffer"].double().sum()) for i in o["state"]], g["momentum_sums"],
+                               rtol=1e-12, atol=0)
+    grp = o["param_groups"][0]
+    assert sorted(grp.keys()) == list(g["group_keys"]) and grp["params"] == list(g["group_params"])
+    assert [grp["lr"], grp["momentum"], grp["dampening"], grp["weight_decay"]] == list(g["group_scalars"])
+    m2 = yt.YOLOv3(num_classes=2)
+    opt2 = torch.optim.SGD(m2.parameters(), lr=0.5, momentum=0.9, weight_decay=5e-4)
+    yt.load_checkpoint(m2, opt2, lr=0.125, filename="ck.pth.tar", model_folder=str(tmp_path))
+    assert all(gr["lr"] == 0.125 for gr in opt2.param_groups)
+    for (k, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k == k2 and torch.equal(a, b), k
+    for pa, pb in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(opt.state[pa]["momentum_buffer"], opt2.state[pb]["momentum_buffer"])

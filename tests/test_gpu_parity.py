@@ -1112,3 +1112,47 @@ def test_two_rank_data_parallel_on_gpu(tmp_path, mode):
     r1 = json.load(open(tmp_path / "rank1.json"))
     assert r0["norms"] == r1["norms"]                                   # same averaged gradients on both ranks
     assert r0["worst_rel_err_vs_mean_of_shards"] < (1e-5 if mode == "fp32" else 1e-5)
+
+
+def test_checkpoint_round_trip_on_device(yt, tmp_path):
+    """save_checkpoint after a real fine-tune step on the GPU, load_checkpoint into a model that has ALREADY run (so its
+    packed-weight cache is warm and must be dropped): same forward, same momentum buffers, learning rate forced; a second
+    step from the restored state equals the second step of the original."""
+    c = gi.NET_CASES["nc2_s128_b1_leaky"]
+    x = onet.synth_input(5, 2, 64).cuda()
+    tgt = [torch.from_numpy(t).cuda() for t in gi.synth_targets(2, 64, c["nc"], gi.TRAIN_CASE["anchors"], 77)]
+    anchors = torch.tensor(gi.TRAIN_CASE["anchors"], dtype=torch.float32).cuda()
+    loss_fn = yt.FusedYOLOLoss()
+
+    def step(m, opt):
+        m.train()
+        opt.zero_grad()
+        preds = m(x)
+        loss = sum(sum(loss_fn(p, t.clone(), anchors[i] * p.shape[2])) for i, (p, t) in enumerate(zip(preds, tgt)))
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    m = _model(yt, c)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    step(m, opt)
+    yt.save_checkpoint(m, opt, filename=str(tmp_path / "ck.pth"))
+    other = dict(c, wseed=c["wseed"] + 1)
+    m2 = _model(yt, other)
+    with torch.no_grad():
+        stale = m2(x)                                           # packs m2's OWN weights
+    opt2 = torch.optim.SGD(m2.parameters(), lr=0.7, momentum=0.9, weight_decay=5e-4)
+    yt.load_checkpoint(m2, opt2, lr=1e-3, filename="ck.pth", model_folder=str(tmp_path))
+    assert all(g["lr"] == 1e-3 for g in opt2.param_groups)
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        a, b = m(x), m2(x)
+    for pa, pb, ps in zip(a, b, stale):
+        assert torch.equal(pa, pb)
+        assert not torch.equal(pb, ps)
+    for pa, pb in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(opt.state[pa]["momentum_buffer"], opt2.state[pb]["momentum_buffer"])
+    l1, l2 = step(m, opt), step(m2, opt2)
+    assert l1 == l2
+    for pa, pb in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(pa, pb)

@@ -17,7 +17,8 @@ import torch
 from . import _lib as L
 
 __all__ = ["iou_aligned", "calc_iou", "cells_to_boxes", "non_max_suppression", "decode_boxes", "nms_indices",
-           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy", "eval_boxes", "get_eval_boxes", "letterbox", "unletterbox_boxes"]
+           "detect", "build_targets", "calc_mAP", "accuracy_counts", "check_model_accuracy", "eval_boxes", "get_eval_boxes", "letterbox", "unletterbox_boxes",
+           "save_checkpoint", "load_checkpoint"]
 
 
 # -------------------------------------------------------------------------------- IoU
@@ -370,3 +371,26 @@ def unletterbox_boxes(boxes, original_hw, resized_hw):
     pad_width, pad_height = (r_w - new_width) // 2, (r_h - new_height) // 2
     return [[(b[0] * r_w - pad_width) / new_width, (b[1] * r_h - pad_height) / new_height, (b[2] * r_w) / new_width,
              (b[3] * r_h) / new_height, b[4], b[5]] for b in boxes]
+
+
+# ------------------------------------------------------------------------ checkpoints
+def save_checkpoint(model, optimizer, filename="YOLOv3TurbineCheckpoint.pth.tar"):
+    """`utils.py:383-396`: ``{"state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}`` through ``torch.save``.
+    The model's 438 ``state_dict`` entries and its parameter order are the reference's, so a file written here loads with
+    the reference's ``load_checkpoint`` and the other way round (pinned by ``tests/golden/checkpoint.npz``)."""
+    torch.save({"state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}, filename)
+
+
+def load_checkpoint(model, optimizer, lr, filename="", model_folder=None, map_location=None):
+    """`utils.py:398-416`: restore model and optimizer, then force every param group's ``lr``. The reference prefixes
+    ``config.MODEL_FOLDER`` and maps to ``config.DEVICE``; there is no global config here, so both are arguments
+    (``model_folder=None``: ``filename`` is the path; ``map_location=None``: the model's own device)."""
+    path = filename if model_folder is None else f"{model_folder}/{filename}"
+    if map_location is None:
+        map_location = next(model.parameters()).device
+    checkpoint = torch.load(path, map_location=map_location)
+    model.load_state_dict(checkpoint["state_dict"])          # invalidates the packed-weight cache (post-hook in model.py)
+    optimizer.load_state_dict(checkpoint["optimizer"])
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = lr
+    print(f"Checkpoint loaded from {filename}")
