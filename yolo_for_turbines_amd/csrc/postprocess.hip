@@ -30,18 +30,21 @@ namespace yolo {
 // ------------------------------------------------------------------------------ decode
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-// One thread per cell (b, a, row, col); col is the fastest thread index so that the reference's
-// permuted view (element stride 1 along col) is read coalesced. For this library's contiguous
-// head layout (stride 1 along k) the 64 cells of a wave are first staged through LDS so global
-// reads are full lines.
+// 256 threads per 64 cells (b, a, row, col): FOUR lanes per cell. For this library's contiguous head layout (stride 1
+// along k) the 64 x (5 + nc) floats of the block are staged through LDS with full-line 16-byte loads by all 256 threads;
+// each of a cell's four lanes then finds the first maximum of a quarter of the class scores and the partial results are
+// combined in class order with the same rule, which is exactly the sequential first-maximum (torch.argmax; NaN counts as
+// the maximum). Lane 0 of the cell finishes it. (One lane per cell and 64-thread blocks left 6-7 waves per CU, each
+// waiting on its own loads and then on 80 dependent LDS reads: 2.5 TB/s.)
 __device__ __forceinline__ void decode_block(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
                                              const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
                                              float* __restrict__ boxes, int n_total, int box_offset, long long blk) {
     extern __shared__ __attribute__((aligned(16))) float tile[];           // [64][D] when sk == 1 && cells contiguous, else unused
     const int D = 5 + nc;
+    const int q = threadIdx.x & 3, cl = threadIdx.x >> 2;
     const long long cells = (long long)B * 3 * g * g;
     const long long cell0 = blk * 64;
-    const long long cell = cell0 + threadIdx.x;
+    const long long cell = cell0 + cl;
     const bool contiguous = (sk == 1 && sx == D && sy == (long long)g * D && sa == (long long)g * g * D &&
                              sb == 3LL * g * g * D);
     const float* src;
@@ -49,47 +52,76 @@ __device__ __forceinline__ void decode_block(float* __restrict__ pred, long long
     if (contiguous) {
         const long long first = cell0 * D;
         const long long count = (cells - cell0 < 64 ? cells - cell0 : 64) * D;
-        // 16-byte loads when the tile is whole (64 * D floats is a multiple of 4 and the base is 16-byte aligned):
-        // 4-byte loads made this pass latency-bound at 1.1 TB/s
         const float* gsrc = pred + first;
         if (count == 64LL * D && ((reinterpret_cast<size_t>(gsrc) & 15) == 0)) {
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const int n4 = (int)(count >> 2);
-#pragma unroll 4
-            for (int i = threadIdx.x; i < n4; i += 64) reinterpret_cast<f4*>(tile)[i] = reinterpret_cast<const f4*>(gsrc)[i];
+            const int n4 = (int)(count >> 2);                                // 1,360 at 80 classes: <= 6 per thread, all in flight
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 6) {
+                f4 r[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (i0 + u * 256 < n4) r[u] = reinterpret_cast<const f4*>(gsrc)[i0 + u * 256];
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (i0 + u * 256 < n4) reinterpret_cast<f4*>(tile)[i0 + u * 256] = r[u];
+            }
         } else {
-            for (long long i = threadIdx.x; i < count; i += 64) tile[i] = gsrc[i];
+            for (long long i = threadIdx.x; i < count; i += 256) tile[i] = gsrc[i];
         }
         __syncthreads();
-        src = tile + (long long)threadIdx.x * D;
+        src = tile + (long long)cl * D;
         kstride = 1;
     } else {
         src = nullptr;
         kstride = sk;
     }
-    if (cell >= cells) return;
+    if (cell >= cells) return;                                               // the four lanes of a cell leave together
     const int col = (int)(cell % g);
     const int row = (int)((cell / g) % g);
     const int a = (int)((cell / ((long long)g * g)) % 3);
     const int b = (int)(cell / (3LL * g * g));
     float* gp = pred + b * sb + a * sa + row * sy + col * sx;
     if (!contiguous) src = gp;
+    float cls;
+    if (is_pred) {
+        const int per = (nc + 3) >> 2;
+        const int k0 = q * per, k1 = k0 + per < nc ? k0 + per : nc;
+        bool have = k0 < k1;
+        int best = k0;
+        float bv = have ? src[(5 + k0) * kstride] : 0.f;
+        int k = k0 + 1;
+        for (; k + 8 <= k1; k += 8) {                    // 8 scores in flight: one LDS round trip per 8 instead of per score
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(5 + k + u) * kstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] > bv || (v[u] != v[u] && bv == bv)) { bv = v[u]; best = k + u; }
+        }
+        for (; k < k1; ++k) {
+            const float v = src[(5 + k) * kstride];
+            if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }
+        }
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {      // lanes q and q + step: the later quarter wins only by the same rule
+            const float ov = __shfl_down(bv, step, 4);
+            const int ob = __shfl_down(best, step, 4);
+            const int oh = __shfl_down((int)have, step, 4);
+            if (oh && (!have || ov > bv || (ov != ov && bv == bv))) { bv = ov; best = ob; have = true; }
+        }
+        cls = (float)best;
+    } else {
+        cls = 0.f;
+    }
+    if (q != 0) return;
     const float inv = (float)(1.0 / (double)g);          // `1 / grid_size` is a Python float, cast to fp32 by the multiply
     float p0 = src[0], p1 = src[kstride], p2 = src[2 * kstride], p3 = src[3 * kstride], p4 = src[4 * kstride];
-    float cls;
     if (is_pred) {
         p0 = sigmoid_f(p0);
         p1 = sigmoid_f(p1);
         p2 = expf(p2) * anchors[2 * a];
         p3 = expf(p3) * anchors[2 * a + 1];
         p4 = sigmoid_f(p4);
-        int best = 0;
-        float bv = src[5 * kstride];
-        for (int k = 1; k < nc; ++k) {                   // first maximum; NaN counts as maximum (torch.argmax)
-            const float v = src[(5 + k) * kstride];
-            if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }
-        }
-        cls = (float)best;
         gp[0] = p0; gp[sk] = p1; gp[2 * sk] = p2; gp[3 * sk] = p3;   // in-place side effect (utils.py:106-110)
     } else {
         cls = src[5 * kstride];
@@ -689,7 +721,7 @@ int yolo_decode(void* pred, const int64_t* s, const float* anchors, int b, int g
     const int D = 5 + nc;
     const size_t lds = (size_t)64 * D * sizeof(float);
     if (lds > 64 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "decode: %d classes exceed the staging tile", nc);
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(64), lds, (hipStream_t)stream, (float*)pred,
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (float*)pred,
                        (long long)s[0], (long long)s[1], (long long)s[2], (long long)s[3], (long long)s[4], anchors, b, g, nc,
                        is_pred, boxes, n_total, box_offset);
     return check_launch("decode");
@@ -715,7 +747,7 @@ int yolo_decode3(void* const* preds3, const int64_t* strides15, const float* con
     if (blocks > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "decode3: too many cells");
     const size_t lds = (size_t)64 * (5 + nc) * sizeof(float);
     if (lds > 64 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "decode: %d classes exceed the staging tile", nc);
-    hipLaunchKernelGGL(decode3_kernel, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(decode3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("decode3");
 }
 
