@@ -652,10 +652,17 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
                 for (int c = rb + 1 + lane; c <= rb1; c += 64) {
                     if (lo[c] > hi_r) break;            // never written: classes above this row block's
                     unsigned long long acc = 0ull, wk = work;
-                    while (wk) {
-                        const int t = __builtin_ctzll(wk);
-                        wk &= wk - 1ull;
-                        acc |= mk[(size_t)(rb * 64 + t) * W + c];
+                    while (wk) {                        // four rows' words in flight (a spent slot repeats the last row)
+                        int t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            t[u] = wk ? __builtin_ctzll(wk) : t[u ? u - 1 : 0];
+                            wk &= wk - 1ull;
+                        }
+                        unsigned long long w4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) w4[u] = mk[(size_t)(rb * 64 + t[u]) * W + c];
+                        acc |= (w4[0] | w4[1]) | (w4[2] | w4[3]);
                     }
                     if (acc) removed[c] |= acc;         // this lane owns word c of this wave's array
                 }
