@@ -42,6 +42,7 @@ struct ConvHArgs {
     int Cin, Cout;
     int x_ld, x_off, y_ld, y_off, r_ld, r_off;
     int TH, TW, PC, patch_cap;
+    int bufmask, mtab_off;   // bufmask 1: two patch buffers; 0: one (stride-2 3x3, see launch_h). mtab_off: byte offset of mtab in LDS
     int tiles_w, tiles_n, nblocks;
     int KT, nchunks;
     int act, out_mode, flags, nc5;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void h_kstep(const ConvHArgs& p, const HCtx<T, TN>& c
     __builtin_amdgcn_sched_barrier(0);
     constexpr int kh = TAP / KS, kw = TAP % KS;
     constexpr int nkh = (TAP + 1) / KS, nkw = (TAP + 1) % KS;
-    const char* Ab_next = patch + (chunk & 1) * (p.patch_cap * H_PIX_BYTES) + (nkh * p.PC + nkw) * H_PIX_BYTES;
+    const char* Ab_next = patch + (chunk & p.bufmask) * (p.patch_cap * H_PIX_BYTES) + (nkh * p.PC + nkw) * H_PIX_BYTES;
     (void)kh; (void)kw;
     // A fragments of this step were read during the previous one (af); read the next step's now
     u32x4 an[2][2];
@@ -141,14 +142,15 @@ __device__ __forceinline__ void h_kstep(const ConvHArgs& p, const HCtx<T, TN>& c
 #pragma unroll
         for (int s = 0; s < 2; ++s) af[i][s] = an[i][s];
     if (TAP == TAPS - 1) {
-        char* dst = patch + ((chunk + 1) & 1) * (p.patch_cap * H_PIX_BYTES) + (tid >> 2) * H_PIX_BYTES + (tid & 3) * 16;
+        if (!p.bufmask) __syncthreads();             // one buffer: every wave has finished reading this chunk
+        char* dst = patch + ((chunk + 1) & p.bufmask) * (p.patch_cap * H_PIX_BYTES) + (tid >> 2) * H_PIX_BYTES + (tid & 3) * 16;
 #pragma unroll
         for (int i = 0; i < H_NI; ++i) {
             u32x4 z = {0u, 0u, 0u, 0u};
             if ((tid >> 2) + 64 * i < p.patch_cap) *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
         }
         __syncthreads();
-        const char* An = patch + ((chunk + 1) & 1) * (p.patch_cap * H_PIX_BYTES);
+        const char* An = patch + ((chunk + 1) & p.bufmask) * (p.patch_cap * H_PIX_BYTES);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -320,8 +322,8 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     constexpr int TN = BN / 64;
     static_assert(MASK == 0 || (KS == 3 && STRIDE == 1), "tap subsets are defined on the 3x3 stride-1 window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* patch = smem_raw;                                             // [2][patch_cap][80 B]
-    int* mtab = reinterpret_cast<int*>(patch + 2 * p.patch_cap * H_PIX_BYTES);
+    char* patch = smem_raw;                                             // [2 or 1][patch_cap][80 B]
+    int* mtab = reinterpret_cast<int*>(patch + p.mtab_off);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -755,7 +757,14 @@ static int launch_h(ConvHArgs& a, hipStream_t s) {
     a.first_wave = 2 * 256;
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;      // one block's matrix cycles per wave
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;   // s_sleep 32 = 2048 cycles
-    const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
+    // Stride-2 3x3: the patch of 128 output pixels is ~500 input pixels, and two buffers of it (82 KB) leave ONE block per
+    // CU (measured: >= 82 KB -> 1, 42-52 KB -> 3), i.e. nothing to overlap a block's staging and epilogue with. One buffer
+    // + one more barrier per 32-channel chunk instead; the region also holds the epilogue's 128 x 68 fp32 staging tile.
+    a.bufmask = (KS == 3 && STRIDE == 2) ? 0 : 1;
+    size_t patch_bytes = (size_t)(a.bufmask + 1) * a.patch_cap * H_PIX_BYTES;
+    if (patch_bytes < 128 * 68 * sizeof(float)) patch_bytes = 128 * 68 * sizeof(float);
+    a.mtab_off = (int)patch_bytes;
+    const size_t lds = patch_bytes + 128 * sizeof(int);
     if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, KS, STRIDE>), dim3(a.nblocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_patch_h16<T, KS, STRIDE, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16");
@@ -770,7 +779,9 @@ static int launch_cls(ConvHArgs& a, hipStream_t s) {
     a.first_wave = 2 * 256;
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
-    const size_t lds = (size_t)2 * a.patch_cap * H_PIX_BYTES + 128 * sizeof(int);
+    a.bufmask = 1;
+    a.mtab_off = 2 * a.patch_cap * H_PIX_BYTES;
+    const size_t lds = (size_t)a.mtab_off + 128 * sizeof(int);
     if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, 3, 1, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_patch_h16<T, 3, 1, BN, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16 (dgrad s2 class)");
