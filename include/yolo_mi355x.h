@@ -83,6 +83,11 @@ size_t yolo_packed_weight_elems(int cout, int cin, int ksize);
  * v_mfma_f32_32x32x16_{f16,bf16}: [cout_pad128/32][cin/32][k*k][2][64 lanes][8 halfs] (cin % 32 == 0). */
 size_t yolo_packed_weight_bytes(int cout, int cin, int ksize, int dtype);
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream);
+/* Many layers at once (every weight tensor changes at `optimizer.step()`, train.py:68): items is a HOST array. 16-bit dtypes:
+ * one launch per 48 items. dgrad = 0: the layout of yolo_pack_weights; dgrad = 1: of yolo_pack_weights_dgrad(flip = 1)
+ * (stride-1 layers only). fp32: the per-item functions are called in turn. */
+typedef struct yolo_pack_item { const float* w_oihw; void* w_packed; int cout, cin, ksize, reserved; } yolo_pack_item;
+int yolo_pack_weights_batch(const yolo_pack_item* items, int n, int dgrad, int dtype, void* stream);
 /* inverse (for gradients / checkpoint export): packed -> OIHW */
 int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream);
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (nn.BatchNorm2d eval,

@@ -17,6 +17,12 @@ OUT_NHWC, OUT_UPSAMPLE2X, OUT_HEAD = 0, 1, 2
 FLAG_RESIDUAL, FLAG_NANCHECK = 1, 2
 
 
+class PackItem(C.Structure):
+    """`yolo_pack_item` (include/yolo_mi355x.h)."""
+    _fields_ = [("w_oihw", C.c_void_p), ("w_packed", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("ksize", C.c_int),
+                ("reserved", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "h", "w", "cin", "cout", "ksize", "stride", "x_ld", "x_off", "y_ld", "y_off", "r_ld", "r_off",
@@ -70,6 +76,7 @@ _SIGS = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "yolo_debug_tr_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_packed_dgrad_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "yolo_pack_weights_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "yolo_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "yolo_conv_dgrad_s2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -177,6 +177,8 @@ int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, cons
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
 int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);
+int h16_pack_batch(const float* const* w, void* const* wf, const int* cout, const int* cin, const int* ks, int n, int dgrad, int dtype,
+                   hipStream_t s);
 size_t h16_dgrad_s2_elems(int cout, int cin);
 int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtype, hipStream_t s);
 int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, const void* residual, int r_ld, int r_off, void* dx,

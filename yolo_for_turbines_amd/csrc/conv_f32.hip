@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------ host side
-struct TileCfg { int bm, bn; };
-static const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+
+
 constexpr int kNumTiles = 7;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU)
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }

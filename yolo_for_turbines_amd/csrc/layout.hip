@@ -170,6 +170,29 @@ int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, in
     return v2_pack(w_oihw, (float*)w_packed + total, cout, cin, ksize, (hipStream_t)stream);
 }
 
+int yolo_pack_weights_batch(const yolo_pack_item* items, int n, int dgrad, int dtype, void* stream) {
+    if (n < 0 || (n > 0 && !items)) return fail(YOLO_ERR_ARG, "pack_weights_batch: bad arguments");
+    if (dtype != YOLO_F16 && dtype != YOLO_BF16) {            // fp32 layouts: one launch (pair) per item as before
+        for (int i = 0; i < n; ++i) {
+            const yolo_pack_item& q = items[i];
+            const int rc = dgrad ? yolo_pack_weights_dgrad(q.w_oihw, q.w_packed, q.cout, q.cin, q.ksize, 1, dtype, stream)
+                                 : yolo_pack_weights(q.w_oihw, q.w_packed, q.cout, q.cin, q.ksize, dtype, stream);
+            if (rc) return rc;
+        }
+        return YOLO_OK;
+    }
+    if (n > 4096) return fail(YOLO_ERR_ARG, "pack_weights_batch: too many items");
+    const float* w[4096]; void* wf[4096]; int cout[4096], cin[4096], ks[4096];
+    for (int i = 0; i < n; ++i) {
+        const yolo_pack_item& q = items[i];
+        if (!q.w_oihw || !q.w_packed) return fail(YOLO_ERR_ARG, "pack_weights_batch: null pointer in item %d", i);
+        const size_t bytes = dgrad ? yolo_packed_dgrad_bytes(q.cout, q.cin, q.ksize, 1, dtype) : yolo_packed_weight_bytes(q.cout, q.cin, q.ksize, dtype);
+        if (!bytes) return fail(YOLO_ERR_UNSUPPORTED, "pack_weights_batch: item %d (%d->%d k%d) has no 16-bit layout", i, q.cin, q.cout, q.ksize);
+        w[i] = q.w_oihw; wf[i] = q.w_packed; cout[i] = q.cout; cin[i] = q.cin; ks[i] = q.ksize;
+    }
+    return h16_pack_batch(w, wf, cout, cin, ks, n, dgrad, dtype, (hipStream_t)stream);
+}
+
 int yolo_unpack_weights(const void* w_packed, float* w_oihw, int cout, int cin, int ksize, int dtype, void* stream) {
     if (!w_oihw || !w_packed) return fail(YOLO_ERR_ARG, "unpack_weights: null pointer");
     if (dtype != YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "unpack_weights: dtype %d", dtype);

@@ -211,14 +211,15 @@ class PackedBlock:
             ts.append(block.conv.bias)
         return tuple((t.data_ptr(), t._version) for t in ts)
 
-    def refresh(self, block, stream, fold_bn=True):
-        """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold."""
+    def refresh(self, block, stream, fold_bn=True, conv_packed=False):
+        """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold.
+        conv_packed: the conv weights were already written by a batched pack (ModelState.refresh_weights)."""
         lib = L.lib()
         cv = block.conv
         w = cv.weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
-        if self.packs_conv:
+        if self.packs_conv and not conv_packed:
             L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
                                           cv.kernel_size[0], self.code, stream), "yolo_pack_weights")
         if self.stem_w is not None:
@@ -404,10 +405,26 @@ class ModelState:
         return pk
 
     def refresh_weights(self, blocks, device, stream, dtype="fp32", fold_bn=True):
+        stale = []
         for blk in blocks:
             pk = self.packed(blk, device, dtype)
             if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk) or (fold_bn and not pk.folded):
-                pk.refresh(blk, stream, fold_bn)
+                stale.append((blk, pk))
+        # 16-bit: all stale conv weights in one launch per 48 layers (after an optimizer step that is every layer)
+        batched = set()
+        if dtype != "fp32" and len(stale) > 1:
+            items, keep = [], []
+            for blk, pk in stale:
+                cv, w = blk.conv, blk.conv.weight.detach()
+                if pk.packs_conv and w.dtype == torch.float32 and w.is_contiguous():
+                    items.append(L.PackItem(w.data_ptr(), pk.w.data_ptr(), cv.out_channels, cv.in_channels, cv.kernel_size[0], 0))
+                    keep.append(id(pk))
+            if items:
+                arr = (L.PackItem * len(items))(*items)
+                L.check(L.lib().yolo_pack_weights_batch(C.cast(arr, C.c_void_p), len(items), 0, _DT[dtype][0], stream), "yolo_pack_weights_batch")
+                batched = set(keep)
+        for blk, pk in stale:
+            pk.refresh(blk, stream, fold_bn, conv_packed=id(pk) in batched)
 
     # ------------------------------------------------------------------ inference forward
     def forward(self, model, x):

@@ -103,6 +103,7 @@ def _forward(state, model, plan: TrainPlan, x):
     L.check(lib.yolo_nchw_to_nhwc(xin.data_ptr(), plan.ybuf[inp.buf].data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], inp.ld,
                                   code, plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
     preds = [None] * prog.n_pred
+    tracked = []                                         # num_batches_tracked counters: ONE foreach launch, not 72
     for i, op in enumerate(prog.ops):
         blk, cv = op["block"], op["block"].conv
         pk = state.packed(blk, dev, plan.dtype)
@@ -134,12 +135,14 @@ def _forward(state, model, plan: TrainPlan, x):
                                   st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), code,
                                   plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
         if track:
-            bn.num_batches_tracked += 1
+            tracked.append(bn.num_batches_tracked)
         flag_ptr = plan.nan_flag.data_ptr() if (op["flags"] & L.FLAG_NANCHECK) else 0
         L.check(lib.yolo_bn_act_fwd(z.data_ptr(), cout, 0, st[0].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
                                     plan.view_ptr(rv) if rv is not None else 0, rv.ld if rv is not None else 0,
                                     rv.off if rv is not None else 0, plan.view_ptr(yv), yv.ld, yv.off, B, op["Ho"], op["Wo"],
                                     cout, _act_code(blk), op["out_mode"], code, flag_ptr, stream), "yolo_bn_act_fwd")
+    if tracked:
+        torch._foreach_add_(tracked, 1)
     return preds
 
 
@@ -249,6 +252,29 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
         return any(need.get(id(q), False) for q in ps)
     first_needed = 0 if want_input_grad else next((j for j, o in enumerate(prog.ops) if _trainable(o)), len(prog.ops))
 
+    def wants_dgrad(i, op):
+        return (op["x"].buf != prog.input.buf or want_input_grad) and i > first_needed - (1 if want_input_grad else 0)
+
+    # 16-bit: the input-gradient weights of all stride-1 layers in one launch per 48 layers (they only depend on the master
+    # weights, which do not change between forward and backward)
+    prepacked = set()
+    if plan.dtype != "fp32":
+        items = []
+        for i in range(first_needed, len(prog.ops)):
+            op = prog.ops[i]
+            cv = op["block"].conv
+            w = cv.weight.detach()
+            if op["s"] == 1 and wants_dgrad(i, op) and w.dtype == torch.float32 and w.is_contiguous():
+                wp = plan.dgrad_w.get(i)
+                if wp is None:
+                    wp = plan.dgrad_w[i] = torch.empty(lib.yolo_packed_dgrad_bytes(cv.out_channels, cv.in_channels, op["k"], 1, code),
+                                                       dtype=torch.uint8, device=dev)
+                items.append(L.PackItem(w.data_ptr(), wp.data_ptr(), cv.out_channels, cv.in_channels, op["k"], 0))
+                prepacked.add(i)
+        if items:
+            arr = (L.PackItem * len(items))(*items)
+            L.check(lib.yolo_pack_weights_batch(C.cast(arr, C.c_void_p), len(items), 1, code, stream), "yolo_pack_weights_batch(dgrad)")
+
     for i in range(len(prog.ops) - 1, first_needed - 1, -1):
         op = prog.ops[i]
         blk, cv = op["block"], op["block"].conv
@@ -308,15 +334,16 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             grads[id(cv.weight)] = dw
             done(cv.weight)
         # ---------------------------------------------------------------- dgrad into the input's gradient
-        if (xv.buf != prog.input.buf or want_input_grad) and i > first_needed - (1 if want_input_grad else 0):
+        if wants_dgrad(i, op):
             # (the image itself needs no gradient — train.py never asks — and neither does anything under a frozen prefix)
             w = cv.weight.detach()
             flip = 1 if s == 1 else 0
             wp = plan.dgrad_w.get(i)
             if wp is None:
                 wp = plan.dgrad_w[i] = torch.empty(lib.yolo_packed_dgrad_bytes(cout, cin, k, flip, code), dtype=torch.uint8, device=dev)
-            L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), wp.data_ptr(), cout, cin, k, flip, code, stream),
-                    "yolo_pack_weights_dgrad")
+            if i not in prepacked:
+                L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), wp.data_ptr(), cout, cin, k, flip, code, stream),
+                        "yolo_pack_weights_dgrad")
             optr, old, ooff, rptr, rld, roff = G.target(xv)
             if s == 1:
                 coutp = (cout + 31) // 32 * 32
