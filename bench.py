@@ -321,8 +321,8 @@ def main():
             e = entry(t_f, name, "FusedYOLOLoss (3 HIP kernels per scale; same values/gradients as loss.py:29-81)")
             t_p = ydist.timed_steps(make_step(yt.YOLOLoss(), autocast_dtype), args.train_steps, 2, dist, device)
             e["with_pytorch_loss"] = entry(t_p, name, "YOLOLoss (the reference's boolean-mask PyTorch ops)")
-            if world == 1:
-                try:
+            if dist is None:                            # no process group: capture never sees a collective (a forced 1-rank
+                try:                                    # RCCL group inside a capture crashed once in ~10 runs)
                     t_g = graph_leg(autocast_dtype)
                     e["hip_graph"] = entry(t_g, name, "FusedYOLOLoss; whole step replayed as one HIP graph")
                 except Exception as ex:                 # capture is an optimisation, never the measured default
