@@ -28,6 +28,9 @@ class GraphedTrainStep:
                  zero_grad=True):
         if not x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors (no CPU fallback)")
+        if getattr(model._engine, "ddp", None) is not None and model._engine.ddp[0] is not None:
+            raise NotImplementedError("GraphedTrainStep does not capture the data-parallel gradient all-reduce (RCCL inside a HIP "
+                                      "graph capture is not validated here); replay per rank is single-GPU only")
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn if loss_fn is not None else FusedYOLOLoss()
         self.autocast_dtype = autocast_dtype
