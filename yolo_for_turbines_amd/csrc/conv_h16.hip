@@ -948,9 +948,10 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     a.KT = a.nchunks * d->ksize * d->ksize;
     a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
     a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
-    // measured (tools/conv_bench.py --dtype bf16, batch 32): 1x1 and the large-spatial 3x3 layers are
-    // latency/HBM-bound and want more, smaller blocks (BN = 64); 3x3 at <= 52x52 gains from BN = 128
-    const int auto_bn = (d->ksize == 3 && d->cout > 64 && a.Ho <= 52) ? 128 : 64;
+    // measured (tools/conv_bench.py --dtype bf16 --tile 5,6, batch 32): 1x1 layers are latency/HBM-bound and want more,
+    // smaller blocks (BN = 64); every 3x3 with more than 64 output channels gains from BN = 128 (64->128 @104: 81 vs 98 us,
+    // 64->128 s2 @208: 119 vs 131 us, 13x13 .. 52x52: 15-20 %) - the earlier "only up to 52x52" rule predated the epilogue fixes
+    const int auto_bn = (d->ksize == 3 && d->cout > 64) ? 128 : 64;   // same-box A/B of the whole forward: +0.7 % at 416x416, +3.8 % at 608x608
     const int bn = d->tile == 5 ? 64 : (d->tile == 6 ? 128 : auto_bn);
     if (d->dtype == YOLO_BF16) return dispatch_h<__bf16>(a, d->ksize, d->stride, bn, s);
     return dispatch_h<_Float16>(a, d->ksize, d->stride, bn, s);
