@@ -256,13 +256,17 @@ __device__ __forceinline__ void h_chunk_m(const ConvHArgs& p, const HCtx<T, TN>&
     }
 }
 
-// 1x1: one tap per chunk -> unroll three chunks so the ring index stays compile-time
+// 1x1: one tap per chunk -> unroll three chunks so the ring index stays compile-time. Activations are fetched TWO chunks
+// ahead into a 3-slot register rotation (slots = pairs of stage[]): a chunk is only 8-16 MFMAs (~300 cycles), so with the
+// usual one-chunk distance every chunk waited out a full L2 round trip (stamps: 700-1300 cycles per chunk).
 template <typename T, int TN, int R>
 __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN>& c, int chunk, char* patch,
                                             u32x4 (&ring)[3][2][TN], u32x4 (&stage)[H_NI], u32x4 (&af)[2][2],
                                             f32x16 (&acc)[2][TN], int tid) {
     typedef typename HTraits<T>::vec vec;
     constexpr int CUR = R % 3, NXT2 = (R + 2) % 3;
+    constexpr int S_LOAD = ((R + 2) % 3) * 2, S_WRITE = ((R + 1) % 3) * 2;      // chunk + 2 arrives, chunk + 1 goes to LDS
+    static_assert(H_NI >= 6, "three 2-entry slots");
     const int kta = chunk + 2 < c.KT ? chunk + 2 : c.KT - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -270,12 +274,12 @@ __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN
         for (int j = 0; j < TN; ++j)
             ring[NXT2][s][j] = *reinterpret_cast<const u32x4*>(c.wfrag[j] + ((size_t)kta * 2 + s) * 512);
     {
-        const int cn = chunk + 1 < p.nchunks ? chunk + 1 : chunk;
+        const int cn = chunk + 2 < p.nchunks ? chunk + 2 : p.nchunks - 1;
         const int coff = p.x_off + cn * 32 + (tid & 3) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                   // 1x1 patch = 128 pixels = 2 passes of 64
             const int px = c.pix[i] < 0 ? 0 : c.pix[i];
-            stage[i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
+            stage[S_LOAD + i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -291,7 +295,7 @@ __device__ __forceinline__ void h_kstep_1x1(const ConvHArgs& p, const HCtx<T, TN
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
+        *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[S_WRITE + i];
     }
     __syncthreads();
     const char* An = patch + ((chunk + 1) & 1) * (p.patch_cap * H_PIX_BYTES);
@@ -441,6 +445,15 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
         for (int i = 0; i < H_NI; ++i) {
             u32x4 z = {0u, 0u, 0u, 0u};
             if ((tid >> 2) + 64 * i < p.patch_cap) *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
+        }
+    }
+    if constexpr (KS == 1 && MASK == 0) {             // 1x1: chunk 1 into register slot 1 (h_kstep_1x1 runs two chunks ahead)
+        const int cn = 1 < p.nchunks ? 1 : 0;
+        const int coff = p.x_off + cn * 32 + (tid & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = c.pix[i] < 0 ? 0 : c.pix[i];
+            stage[2 + i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
         }
     }
     __syncthreads();
