@@ -156,7 +156,10 @@ def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
     return {"workload": f"batch {batch}, {size}x{size}, {nc} classes: {n_total} boxes/image, 3 scales in 1 launch", "ms": round(ms, 4),
             "boxes_per_s": round(batch * n_total / ms * 1e3, 1), "algorithmic_bytes": nbytes,
             "roofline": {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(nbytes / ms / 1e6 / 8000.0, 4)}}
+                         "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
+                         # PMC passes of tools/decode_bench.py (profiles/r01/pmc_hbm_traffic.txt): FETCH_SIZE x2-corrected
+                         # 116.0 MB + WRITE_SIZE 23.3 MB per launch at batch 32, 416x416, 80 classes
+                         "traffic": 139.3e6 if (batch, size, nc) == (32, 416, 80) else None}}
 
 
 COCO_ANCHORS = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
