@@ -1156,3 +1156,36 @@ def test_checkpoint_round_trip_on_device(yt, tmp_path):
     assert l1 == l2
     for pa, pb in zip(m.parameters(), m2.parameters()):
         assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_batched_weight_pack_equals_per_layer_pack(yt, dtype):
+    """yolo_pack_weights_batch (one launch per 48 layers, used after every optimizer step) writes byte-identical buffers to
+    the per-layer yolo_pack_weights / yolo_pack_weights_dgrad(flip = 1), for forward and input-gradient layouts, incl.
+    a head-like layer whose channel count is padded; more than 48 items exercise the chunking."""
+    import ctypes as C
+    from yolo_for_turbines_amd import _lib as L
+    lib = L.lib()
+    code = {"bf16": L.BF16, "fp16": L.F16}[dtype]
+    shapes = [(64, 32, 3), (128, 64, 3), (32, 64, 1), (256, 128, 3), (24, 256, 1), (255, 512, 1), (512, 256, 3)] * 8     # 56 items
+    gen = torch.Generator().manual_seed(5)
+    ws = [torch.randn((co, ci, k, k), generator=gen).cuda() for co, ci, k in shapes]
+    st = L.current_stream()
+    for dgrad in (0, 1):
+        single, batch, items = [], [], []
+        for w, (co, ci, k) in zip(ws, shapes):
+            n = lib.yolo_packed_dgrad_bytes(co, ci, k, 1, code) if dgrad else lib.yolo_packed_weight_bytes(co, ci, k, code)
+            assert n > 0
+            a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            b = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+            if dgrad:
+                L.check(lib.yolo_pack_weights_dgrad(w.data_ptr(), a.data_ptr(), co, ci, k, 1, code, st), "single dgrad pack")
+            else:
+                L.check(lib.yolo_pack_weights(w.data_ptr(), a.data_ptr(), co, ci, k, code, st), "single pack")
+            single.append(a); batch.append(b)
+            items.append(L.PackItem(w.data_ptr(), b.data_ptr(), co, ci, k, 0))
+        arr = (L.PackItem * len(items))(*items)
+        L.check(lib.yolo_pack_weights_batch(C.cast(arr, C.c_void_p), len(items), dgrad, code, st), "batch pack")
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(single, batch)):
+            assert torch.equal(a, b), (dgrad, i, shapes[i])
