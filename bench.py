@@ -227,6 +227,42 @@ def aux_legs(yt, device, result, world, args):
         result["map"]["cpu_port_sample"] = f"first 16 images ({len(sub_p)} detections), oracle/metrics.py restatement of calc_mAP"
 
 
+def launch_argv(n_gpus, port, script_args):
+    """Command line of the N-rank child: the launcher of the bench contract, this script, the caller's own flags."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(script_args)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    import subprocess
+    script_args = [a for a in sys.argv[1:] if a != "--dry-launch"]
+    argv = launch_argv(args.gpus, int(os.environ.get("MASTER_PORT") or free_port()), script_args)
+    if args.dry_launch:
+        print(json.dumps({"argv": argv}))
+        return 0
+    n_dev = torch.cuda.device_count()                      # counting devices does not initialise the GPU
+    if n_dev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {n_dev} GPU(s)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    log(f"starting {args.gpus} ranks: {' '.join(argv)}")
+    child = subprocess.run(argv, env=env, stdout=subprocess.PIPE, text=True)     # stderr passes through
+    lines = [ln for ln in child.stdout.splitlines() if ln.lstrip().startswith("{")]
+    if child.returncode != 0 or not lines:
+        sys.stderr.write(child.stdout)
+        raise SystemExit(child.returncode or 1)
+    print(lines[-1], flush=True)                           # rank 0's ONE JSON line
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,7 +284,17 @@ def main():
                     help="skip BASELINE config 3 shape: batch 64 multi-scale fine-tune steps (S cycles through 320..608)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
     ap.add_argument("--train-classes", type=int, default=2, help="fine-tune head (BASELINE configs[2-3]: 2-class turbine head)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 outside torchrun: print the child command line (JSON) instead of starting it")
     args = ap.parse_args()
+
+    # ---- N > 1 from a plain `python bench.py --gpus N`: start the N ranks OURSELVES, as a child process, before anything in
+    # this process touches the GPU (no HIP call, no library load: replacing or forking a GPU-initialised process is not
+    # allowed on this pool). The child is the launcher the contract names (`python -m torch.distributed.run`, one rank per
+    # GPU, rendezvous on 127.0.0.1); its rank 0 prints the single JSON line, which is relayed verbatim, and its exit code
+    # becomes ours. Under torchrun (WORLD_SIZE set) this block is skipped and the process is one of the ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) are sent to
     # stderr for the whole run, the result is written to the saved descriptor at the end.
@@ -261,8 +307,6 @@ def main():
     rank, local_rank, world = ydist.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
@@ -314,6 +358,7 @@ def main():
         def graph_leg(autocast_dtype):                  # the same step captured ONCE into a HIP graph and replayed
             gstep = yt.GraphedTrainStep(tm, opt, sa, x, tg, autocast_dtype=autocast_dtype)
             t_el = ydist.timed_steps(lambda: gstep(x, tg), args.train_steps, 2, dist, device)
+            gstep.release()                             # un-pin the train plan
             del gstep
             return t_el
 
@@ -482,4 +527,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -281,6 +281,39 @@ def gen_train():
     np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
 
 
+TRAIN_GRAD_KEYS = ("layers.0.conv.weight", "layers.10.layers.3.1.conv.weight", "layers.15.pred_block.1.conv.bias",
+                   "layers.22.pred_block.1.conv.bias", "layers.29.pred_block.1.conv.bias",
+                   "layers.0.batch_norm.weight", "layers.0.batch_norm.bias", "layers.6.layers.7.1.batch_norm.weight",
+                   "layers.18.conv.weight", "layers.29.pred_block.1.conv.weight")
+
+
+def gen_train_fp64():
+    """The SAME fine-tune step as gen_train, run by the imported reference in float64 (model.double(), double inputs):
+    the yardstick for the LeakyReLU gradients. LeakyReLU's derivative jumps at 0, so two fp32 implementations disagree on
+    single entries by much more than rounding; what can be asked of an fp32 implementation is that it is about as close to
+    the fp64 result as the reference's own fp32 run is (tests: |ours - fp64| <= 3 |reference fp32 - fp64| + 1e-4 max|g|)."""
+    c = gi.TRAIN_CASE
+    out = {}
+    for tag, act in (("leaky", "leaky_relu"), ("mish", "mish")):
+        sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+        m = ref_net(c["nc"], act, sd).double().train()
+        x = onet.synth_input(c["xseed"], c["batch"], c["size"]).double()
+        tg = [torch.from_numpy(t).double() for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+        grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+        sa = (torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)).double()
+        lf = ref_loss.YOLOLoss()
+        preds = m(x)
+        parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+        parts.sum().backward()
+        out[f"{tag}/loss_parts"] = parts.detach().numpy()
+        g = {k: p.grad for k, p in m.named_parameters()}
+        for k in TRAIN_GRAD_KEYS:
+            out[f"{tag}/grad/{k}"] = g[k].reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy().copy() if g[k].numel() > 4096 else g[k].numpy().copy()
+        out[f"{tag}/gradnorm_all"] = np.array([float(p.grad.norm()) for p in m.parameters()])
+        print("train fp64", tag, parts.detach().numpy().round(6).tolist())
+    np.savez_compressed(os.path.join(OUT, "train_step_fp64.npz"), **out)
+
+
 # -------------------------------------------------------------------------- G8 the KATs
 def gen_kat():
     out = {}
@@ -411,7 +444,7 @@ def gen_checkpoint():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "kat", "targets", "checkpoint"]
+    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "train_fp64", "kat", "targets", "checkpoint"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

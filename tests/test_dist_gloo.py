@@ -109,3 +109,70 @@ def test_gradient_buckets_average_over_ranks():
         assert p.exitcode == 0
     for rank, step, vals in res:
         assert vals == pytest.approx([1.5 * (i + 1) * (step + 1) for i in range(5)])
+
+
+# ------------------------------------------------------------------ bench.py --gpus N starts its own ranks
+def test_bench_self_launch_command_line():
+    """`python bench.py --gpus N` outside torchrun must start `python -m torch.distributed.run --nproc-per-node N ...
+    bench.py <same flags>` as a CHILD process (bench contract); --dry-launch prints that command instead of running it."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2", "--dry-launch"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    argv = json.loads(out.stdout.strip().splitlines()[-1])["argv"]
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    k = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]          # the caller's flags, minus --dry-launch
+    # under torchrun (WORLD_SIZE set) the script is a rank, not a launcher: on this CPU box it stops at the GPU check
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"], env=env2,
+                          capture_output=True, text=True, timeout=300)
+    if not torch.cuda.is_available():
+        assert out2.returncode != 0 and "needs an MI355X" in out2.stderr
+
+
+def test_bench_self_launch_relays_one_json_line(monkeypatch, capsys):
+    """The parent relays exactly rank 0's JSON line (library banners on the child's stdout are dropped) and the exit code."""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    line = json.dumps({"metric": "images/sec at 416x416 (fwd)", "n_gpus": 2, "value": 1.0})
+    monkeypatch.setattr(bench, "launch_argv", lambda n, port, rest: [sys.executable, "-c", f"print('RCCL version banner'); print({line!r})"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    assert bench.self_launch(argparse.Namespace(gpus=2, dry_launch=False)) == 0
+    assert capsys.readouterr().out.strip() == line
+    monkeypatch.setattr(bench, "launch_argv", lambda n, port, rest: [sys.executable, "-c", "import sys; print('{}'); sys.exit(3)"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(argparse.Namespace(gpus=2, dry_launch=False))
+    assert e.value.code == 3
+
+
+def test_gradient_buckets_do_not_alias_a_live_grad():
+    """AccumulateGrad keeps the bucket VIEW as p.grad. If that tensor is still alive at the next backward
+    (zero_grad(set_to_none=False), micro-batch accumulation) the kernels would overwrite it and autograd would add the
+    bucket to itself: begin() must give such a parameter its own copy first."""
+    from yolo_for_turbines_amd.dist import GradBuckets
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(4, 3), (7,), (2, 2, 2)]]
+    gb = GradBuckets(params, None, bucket_mb=1.0)
+    gb.begin(params)
+    for i, p in enumerate(params):
+        gb.view(p).fill_(float(i + 1))
+        gb.ready(p)
+    gb.finish()
+    for p in params:
+        p.grad = gb.view(p)                       # what AccumulateGrad does with the tensor the backward returned
+    params[1].grad = torch.full((7,), 9.0)        # a gradient that does NOT live in the bucket stays untouched
+    keep = params[1].grad
+    gb.begin(params)                              # second backward starts
+    for i, p in enumerate(params):
+        gb.view(p).fill_(100.0)                   # the kernels overwrite the bucket
+    assert params[1].grad is keep
+    for i in (0, 2):
+        assert params[i].grad.data_ptr() != gb.view(params[i]).data_ptr()
+        assert float(params[i].grad.mean()) == float(i + 1)          # old value preserved -> `p.grad += new` is a real sum

@@ -1112,6 +1112,13 @@ def test_two_rank_data_parallel_on_gpu(tmp_path, mode):
     r1 = json.load(open(tmp_path / "rank1.json"))
     assert r0["norms"] == r1["norms"]                                   # same averaged gradients on both ranks
     assert r0["worst_rel_err_vs_mean_of_shards"] < (1e-5 if mode == "fp32" else 1e-5)
+    # later steps of the same process group: p.grad tensors kept alive by zero_grad(set_to_none=False) (they alias the
+    # buckets) must come out as 1x the mean, not 2x; a third backward without zero_grad accumulates on top; freezing /
+    # unfreezing parameters rebuilds the buckets so that every trainable gradient is still exchanged
+    assert r0["norms_again"] == r1["norms_again"]
+    for k, v in r0["worst"].items():
+        assert v < 1e-5, (k, v)
+    assert r0["n_frozen_without_grad"] > 50
 
 
 def test_checkpoint_round_trip_on_device(yt, tmp_path):

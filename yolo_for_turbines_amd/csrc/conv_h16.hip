@@ -57,8 +57,8 @@ struct ConvHArgs {
 // x / d for 0 <= x < 2^31 with mg = ceil(2^32 / d) (d >= 2) or 0 (d == 1): the estimate is q or q + 1, one fix-up
 __device__ __forceinline__ int fdiv(int x, unsigned mg, int d) {
     if (!mg) return x;
-    const int q = (int)__umulhi((unsigned)x, mg);
-    return (long long)q * d > x ? q - 1 : q;
+    const unsigned q = __umulhi((unsigned)x, mg);
+    return (int)(q * (unsigned)d > (unsigned)x ? q - 1 : q);       // q*d <= x + d < 2^32: no 64-bit multiply needed
 }
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
@@ -324,10 +324,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void con
 template <typename T, int KS, int STRIDE, int BN, int MASK>
 __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     constexpr int TN = BN / 64;
+    constexpr int NI = KS == 1 ? 2 : H_NI;                             // staged pixels per 4-lane group that can be live (1x1: 128-pixel patch)
     static_assert(MASK == 0 || (KS == 3 && STRIDE == 1), "tap subsets are defined on the 3x3 stride-1 window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* patch = smem_raw;                                             // [2 or 1][patch_cap][80 B]
-    int* mtab = reinterpret_cast<int*>(patch + p.mtab_off);
+    int* mtab = reinterpret_cast<int*>(patch + p.mtab_off);             // [128] output pixel of tile row, [128] head-layout base
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -349,6 +350,43 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     }
     const int sp = fdiv(bid, p.mg_tn, p.tiles_n);
     const int n_tile = bid - sp * p.tiles_n;
+
+    // ---- prologue. Order matters: a 16-bit block's matrix work is ~9k cycles, so every exposed memory round trip counts.
+    // (1) weight fragments of K steps 0 and 1 and the folded BatchNorm scale / shift need nothing but n_tile: request them
+    //     FIRST, so they travel while the patch indices are computed (the index math used to run in front of every load)
+    HCtx<T, TN> c;
+    c.KT = p.KT;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nt = n_tile * (BN / 32) + j * 2 + wn;          // pass j of the epilogue = 64 CONTIGUOUS channels (full 128-B lines)
+        c.wfrag[j] = p.wf + (size_t)nt * p.KT * 1024 + lane * 8;
+    }
+    u32x4 ring[3][2][TN], stage[H_NI], af[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kq = q < p.KT ? q : p.KT - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                ring[q][s][j] = *reinterpret_cast<const u32x4*>(c.wfrag[j] + ((size_t)kq * 2 + s) * 512);
+    }
+    float sc[TN], sh[TN];                                       // this lane's output channel of pass j: n_tile*BN + j*64 + wn*32 + frow
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        sc[j] = 1.f; sh[j] = 0.f;                              // gradient kernels (MASK): plain accumulation
+        if (!MASK) {
+            const int n = n_tile * BN + j * 64 + wn * 32 + frow;
+            const int ncl = n < p.Cout ? n : p.Cout - 1;       // clamped: unconditional loads
+            sc[j] = p.scale[ncl];
+            sh[j] = p.shift[ncl];
+            if (n >= p.Cout) { sc[j] = 0.f; sh[j] = 0.f; }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // (2) patch geometry. Branch-free: every entry is computed for every lane and invalidated by a select (the nested
+    //     ifs compiled to ~20 exec-mask branches per lane)
     const int r_tile = fdiv(sp, p.mg_tw, p.tiles_w);
     const int w_tile = sp - r_tile * p.tiles_w;
     const int g0 = r_tile * p.TH, c0 = w_tile * p.TW;
@@ -361,93 +399,36 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     };
     const int v0 = vrow(g0);
     const int PR = vrow(g_last) + (KS == 3 ? 3 : 1) - v0;
-
-    HCtx<T, TN> c;
-    c.KT = p.KT;
-    {   // staged patch pixels of this 4-lane group: idx = (tid >> 2) + 64 i. Closed form per entry (two magic divisions):
-        // the incremental version with carry loops was ~800 VALU instructions, 4-6k cycles of a 10k-cycle prologue
 #pragma unroll
-        for (int i = 0; i < H_NI; ++i) {
-            const int idx = (tid >> 2) + 64 * i;
-            const int pr = fdiv(idx, p.mg_PC, p.PC), pc = idx - pr * p.PC;
-            int pix = -1;
-            if (pr < PR) {
-                if (KS == 3) {
-                    const int vv = v0 + pr;
-                    const int n = fdiv(vv, p.mg_Hp, Hp), yy = vv - n * Hp;
-                    const int hi = yy - 1, wi = STRIDE * c0 + pc - 1;
-                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) pix = (n * p.Hin + hi) * p.Win + wi;
-                } else {
-                    const int wi = c0 + pc;
-                    if (wi < p.W) pix = wi;
-                }
-            }
-            c.pix[i] = pix;
+    for (int i = 0; i < H_NI; ++i) c.pix[i] = -1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {   // staged patch pixels of this 4-lane group: idx = (tid >> 2) + 64 i
+        const int idx = (tid >> 2) + 64 * i;
+        const int pr = fdiv(idx, p.mg_PC, p.PC), pc = idx - pr * p.PC;
+        int pix;
+        bool ok;
+        if (KS == 3) {
+            const int vv = v0 + pr;
+            const int n = fdiv(vv, p.mg_Hp, Hp), yy = vv - n * Hp;
+            const int hi = yy - 1, wi = STRIDE * c0 + pc - 1;
+            ok = (pr < PR) & ((unsigned)hi < (unsigned)p.Hin) & ((unsigned)wi < (unsigned)p.Win);
+            pix = (n * p.Hin + hi) * p.Win + wi;
+        } else {
+            pix = c0 + pc;
+            ok = (pr < PR) & (pix < p.W);
         }
+        c.pix[i] = ok ? pix : -1;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pp = wm * 64 + i * 32 + frow;
-        const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
-        const int g = g0 + r;
-        const bool ok = pp < p.TH * p.TW && g <= g_last && c0 + cc < p.W;
-        c.a_off[i] = (ok ? ((vrow(g) - v0) * p.PC + STRIDE * cc) * H_PIX_BYTES : 0) + 16 * fh;
-        if (MASK) c.a_off[i] += ((mask_nth(MASK, 0) / 3) * p.PC + mask_nth(MASK, 0) % 3) * H_PIX_BYTES;
-    }
-    if (tid < 128) {
-        const int r = fdiv(tid, p.mg_TW, p.TW), cc = tid - r * p.TW;
-        const int g = g0 + r;
-        int m = -1;
-        if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
-            if (MASK) {                               // parity class: dx pixel (2r + ph, 2c + pw) of image n
-                const int n = fdiv(g, p.mg_H, p.H), rr = g - n * p.H;
-                m = (n * 2 * p.H + 2 * rr + p.cls_ph) * (2 * p.W) + 2 * (c0 + cc) + p.cls_pw;
-            } else {
-                m = g * p.W + c0 + cc;
-            }
-        }
-        mtab[tid] = m;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nt = n_tile * (BN / 32) + j * 2 + wn;          // pass j of the epilogue = 64 CONTIGUOUS channels (full 128-B lines)
-        c.wfrag[j] = p.wf + (size_t)nt * p.KT * 1024 + lane * 8;
-    }
-
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    u32x4 ring[3][2][TN], stage[H_NI], af[2][2];
-    // prologue: weight fragments of steps 0 and 1, patch of chunk 0
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int kq = q < p.KT ? q : p.KT - 1;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                ring[q][s][j] = *reinterpret_cast<const u32x4*>(c.wfrag[j] + ((size_t)kq * 2 + s) * 512);
-    }
+    // (3) patch of chunk 0 (and, 1x1, of chunk 1 into register slot 1: h_kstep_1x1 runs two chunks ahead)
     {
         const int coff = p.x_off + (tid & 3) * 8;
-        char* dst = patch + (tid >> 2) * H_PIX_BYTES + (tid & 3) * 16;
 #pragma unroll
-        for (int i = 0; i < H_NI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int px = c.pix[i] < 0 ? 0 : c.pix[i];
             stage[i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
         }
-#pragma unroll
-        for (int i = 0; i < H_NI; ++i) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if ((tid >> 2) + 64 * i < p.patch_cap) *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
-        }
     }
-    if constexpr (KS == 1 && MASK == 0) {             // 1x1: chunk 1 into register slot 1 (h_kstep_1x1 runs two chunks ahead)
+    if constexpr (KS == 1 && MASK == 0) {
         const int cn = 1 < p.nchunks ? 1 : 0;
         const int coff = p.x_off + cn * 32 + (tid & 3) * 8;
 #pragma unroll
@@ -456,11 +437,57 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
             stage[2 + i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)px * p.x_ld + coff);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // (4) while those loads are in flight: A-fragment offsets and the tile-row -> output-pixel table of the epilogue
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pp = wm * 64 + i * 32 + frow;
+        const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
+        const int g = g0 + r;
+        const bool ok = (pp < p.TH * p.TW) & (g <= g_last) & (c0 + cc < p.W);
+        c.a_off[i] = (ok ? ((vrow(g) - v0) * p.PC + STRIDE * cc) * H_PIX_BYTES : 0) + 16 * fh;
+        if (MASK) c.a_off[i] += ((mask_nth(MASK, 0) / 3) * p.PC + mask_nth(MASK, 0) % 3) * H_PIX_BYTES;
+    }
+    if (tid < 128) {
+        const int r = fdiv(tid, p.mg_TW, p.TW), cc = tid - r * p.TW;
+        const int g = g0 + r;
+        int m = -1, mh = 0;
+        if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
+            if (MASK) {                               // parity class: dx pixel (2r + ph, 2c + pw) of image n
+                const int n = fdiv(g, p.mg_H, p.H), rr = g - n * p.H;
+                m = (n * 2 * p.H + 2 * rr + p.cls_ph) * (2 * p.W) + 2 * (c0 + cc) + p.cls_pw;
+            } else {
+                m = g * p.W + c0 + cc;
+                if (p.out_mode == YOLO_OUT_HEAD) mh = m + 2 * (m / (p.Ho * p.Wo)) * (p.Ho * p.Wo);   // (img*3)*HoWo + pixel
+            }
+        }
+        mtab[tid] = m;
+        mtab[128 + tid] = mh;
+    }
+    {
+        char* dst = patch + (tid >> 2) * H_PIX_BYTES + (tid & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (i < 3 || (tid >> 2) + 64 * i < p.patch_cap)              // patch_cap >= 224: the first three always fit
+                *reinterpret_cast<u32x4*>(dst + 64 * i * H_PIX_BYTES) = c.pix[i] < 0 ? z : stage[i];
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const u32x4*>(patch + c.a_off[i] + s * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));   // pinned here: not re-loaded in the epilogue
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #ifdef H16_STAMPS
     asm volatile("s_nop 0" ::: "memory");
@@ -493,48 +520,81 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
 #endif
     // ---------------------------------------------------------------------- epilogue (fp32 math)
+    // No memory round trip may sit on the critical path here: scale / shift came with the prologue, the residual rows of
+    // BOTH 64-channel passes are requested before the accumulators go through LDS, and nothing ever waits for a store
+    // (an s_waitcnt vmcnt(0) in front of a late load also waits for every store issued before it).
     const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
-    const int HoWo = p.Ho * p.Wo;
     constexpr int OLD = 68;
     float* ost = reinterpret_cast<float*>(patch);                     // [128][68] fp32 = 34,816 B
     const bool vec_ok = (p.out_mode != YOLO_OUT_HEAD) && (p.Cout % 8 == 0);
     bool saw_nan = false;
-    __syncthreads();
+    __syncthreads();                                                  // every wave is done reading the patch
+    const int c8 = tid & 7;
+    int mrow[4];
+    u32x4 rr[TN][4];
+    if (vec_ok) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) mrow[it] = mtab[(tid >> 3) + 32 * it];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rr[j][it] = z;
+            }
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int n = n_tile * BN + j * 64 + c8 * 8;
+                    const int mc = mrow[it] < 0 ? 0 : mrow[it];
+                    const int ncl = n < p.Cout ? n : 0;             // clamped: unconditional loads, discarded below
+                    rr[j][it] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.r_ld + p.r_off + ncl);
+                }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         {
-            const int n = n_tile * BN + j * 64 + wn * 32 + frow;
-            const bool nv = n < p.Cout;
-            const float sc = nv ? (MASK ? 1.f : p.scale[n]) : 0.f;       // gradient kernels: plain accumulation
-            const float sh = nv ? (MASK ? 0.f : p.shift[n]) : 0.f;
             float* dst = ost + wn * 32 + frow;
             YOLO_SWITCH_ACT(p.act,
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {
                         const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc + sh);
+                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc[j] + sh[j]);
                     })
         }
         __syncthreads();
         if (vec_ok) {
             unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+            const int n = n_tile * BN + j * 64 + c8 * 8;
+            f32x4 va[4], vb[4];
+            if (j == 0 && has_res) {
+                // all residual rows (both passes) are awaited HERE, before the first store is issued: a later wait for a
+                // pass-2 row would be counted against the stores issued in between (one in-order counter for loads and stores)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(rr[jj][it]));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {                           // all LDS reads first: one latency, not four
+                const int row = (tid >> 3) + 32 * it;
+                va[it] = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8);
+                vb[it] = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8 + 4);
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tid + 256 * it;
-                const int row = idx >> 3, c8 = idx & 7;
-                const int m = mtab[row];
-                const int n = n_tile * BN + j * 64 + c8 * 8;
+                const int m = mrow[it];
                 if (m < 0 || n >= p.Cout) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ost + row * OLD + c8 * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                float v[8] = {va[it][0], va[it][1], va[it][2], va[it][3], vb[it][0], vb[it][1], vb[it][2], vb[it][3]};
                 if (has_res) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (size_t)m * p.r_ld + p.r_off + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[e] & 0xffffu));
-                        v[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[e] >> 16));
+                        v[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] & 0xffffu));
+                        v[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] >> 16));
                     }
                 }
                 u32x4 o;
@@ -546,6 +606,7 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
                 if (p.out_mode == YOLO_OUT_NHWC) {
                     *reinterpret_cast<u32x4*>(yo + (size_t)m * p.y_ld + p.y_off + n) = o;
                 } else {
+                    const int HoWo = p.Ho * p.Wo;
                     const int img = m / HoWo;
                     const int rem = m - img * HoWo;
                     const int ho = rem / p.Wo;
@@ -558,7 +619,24 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
                     *reinterpret_cast<u32x4*>(d + (size_t)(W2 + 1) * p.y_ld) = o;
                 }
             }
-        } else {                                    // detection heads: fp32 (B,3,g,g,5+nc); odd channel counts
+        } else if (p.out_mode == YOLO_OUT_HEAD && !has_res) {   // detection heads: fp32 (B,3,g,g,5+nc), channel = a*(5+nc) + k
+            const int col = tid & 63;
+            const int n = n_tile * BN + j * 64 + col;
+            const int head_a = n / p.nc5, head_k = n - head_a * p.nc5;
+            const int HoWo = p.Ho * p.Wo;
+            float* yo = reinterpret_cast<float*>(p.y);
+            if (n < p.Cout) {
+#pragma unroll 8
+                for (int it = 0; it < 32; ++it) {
+                    const int row = (tid >> 6) + 4 * it;
+                    if (mtab[row] < 0) continue;
+                    const float v = ost[row * OLD + col];
+                    if (nan_chk && v != v) saw_nan = true;
+                    yo[(size_t)(mtab[128 + row] + head_a * HoWo) * p.nc5 + head_k] = v;
+                }
+            }
+        } else {                                    // odd channel counts outside the heads (block-level tests)
+            const int HoWo = p.Ho * p.Wo;
             for (int it = 0; it < 32; ++it) {
                 const int idx = tid + 256 * it;
                 const int row = idx >> 6, col = idx & 63;
@@ -601,6 +679,416 @@ __device__ __forceinline__ void conv_patch_h16_body(const ConvHArgs& p) {
         }
     }
 #endif
+}
+
+// =====================================================================================================
+// conv3_dma_h16 — 3x3 stride-1 blocks with EVERY operand delivered by LDS-DMA (global_load_lds_dwordx4).
+//
+// Why (per-block stamps of conv_patch_h16, 128->256 @52x52, batch 32): a block's main loop takes ~19.5k cycles whether
+// or not the second resident block is computing — 2 x the 9.2k cycles of its matrix work. The weight fragments travel
+// L2 -> VGPR with a look-ahead of ~2 K steps (~580 matrix cycles), less than the L2 round trip under load, and a deeper
+// REGISTER ring does not fit. Alone on its SIMDs a wave therefore runs at half rate, so the prologue / epilogue of one
+// block is never covered by the other. Here the weights stream through a D_SLOTS-deep ring in LDS instead (shared by
+// the four waves: half the L2 traffic, D_P K steps = ~1,000 matrix cycles of look-ahead, no staging registers), and the
+// activation patch comes the same way, so the loop contains no register-destination load at all: every wait is a
+// counted s_waitcnt vmcnt(N) in front of ONE raw s_barrier per K step (cdna_hip_programming.md "Pipelining across
+// barriers"; a __syncthreads() would drain the DMA queue).
+//   LDS: [2][256 px][64 B] patch (chunk double buffer) | [D_SLOTS][BN/32][2 KiB] weight ring | tile-row tables.
+//   * patch rows are 64 B (32 channels) with the 16-byte granules XOR-swizzled by (pixel >> 2) & 3: an LDS-DMA image is
+//     lane-linear, so the swizzle is applied to the per-lane SOURCE address and again in the fragment read; 16
+//     consecutive pixels then cover all 16 granule slots of the 256-B bank row (conflict-free ds_read_b128);
+//   * halo pixels outside the image read a zero page (g_zero_page) instead of being masked;
+//   * the weight ring holds the fragment-order stream as it lies in HBM: wave w copies n-tile w of the block, every
+//     wave reads its B fragments back lane-linearly.
+//   K step t:  [DMA weights t+D_P] [tap 4: DMA patch of the next chunk] [ds_read A/B of step t+1] [8 MFMAs of step t]
+//              [s_waitcnt vmcnt: own DMAs of step t+2 landed] [s_barrier].
+// =====================================================================================================
+constexpr int D_NI = 4;                          // patch DMA rounds of 64 pixels
+constexpr int D_PATCH_PIX = 64 * D_NI;           // 256 pixels
+constexpr int D_PATCH_BYTES = D_PATCH_PIX * 64;  // 16 KiB per buffer
+constexpr int D_P = 4;                           // weight K steps in flight
+constexpr int D_SLOTS = D_P + 1;
+constexpr int D_PF_TAP = 4;                      // tap at which the next chunk's patch is requested
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[1024 + 16];   // 4 KiB + 64 B of zeros: Cin <= 2048
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int TN>
+struct DCtx {
+    const unsigned short* wsrc;      // this wave's n-tile of the fragment stream (+ lane * 8)
+    const unsigned short* psrc[D_NI];// this lane's source granule of patch round i, chunk 0
+    int p0[2];                       // patch pixel (tap 0,0) of this lane's row in m-tile 0 / 1
+    int KT, PC;
+};
+
+template <typename T, int BN, int TAP>
+__device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
+                                        int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
+                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
+    typedef typename HTraits<T>::vec vec;
+    constexpr int TN = BN / 64;
+    constexpr int SLOT_BYTES = (BN / 32) * 2048;
+    const int t = chunk * 9 + TAP;
+    // (1) weights of step t + D_P -> ring slot slot_w (always issued, source clamped: the wait counts below stay uniform)
+    {
+        const int kt = t + D_P < c.KT ? t + D_P : c.KT - 1;
+        const unsigned short* src = c.wsrc + (size_t)kt * 1024;
+        char* dst = wring + slot_w * SLOT_BYTES + wave * 2048;
+        glds16(src, dst);
+        glds16(src + 512, dst + 1024);
+        slot_w = slot_w + 1 == D_SLOTS ? 0 : slot_w + 1;
+    }
+    // (2) patch of the next chunk
+    if (TAP == D_PF_TAP) {
+        const int cn = chunk + 1 < p.nchunks ? chunk + 1 : chunk;
+        char* dst = patch + ((chunk + 1) & 1) * D_PATCH_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < D_NI; ++i) glds16(c.psrc[i] + cn * 32, dst + i * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (4a) first half of step t's matrix work (k16 step 0). The fragment reads of step t + 1 are issued BEHIND it: hipcc
+    //      drains lgkmcnt to 0 in front of an MFMA group that follows LDS reads while an LDS-DMA is pending (it cannot
+    //      count the two queues apart), so reads placed in front of the group would be waited for at once
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const vec b = __builtin_bit_cast(vec, bf[0][j]);
+        acc[0][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[0][0]), b, acc[0][j]);
+        acc[1][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[1][0]), b, acc[1][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (3) fragments of step t + 1 (landed and made visible by the wait + barrier that closed step t - 1)
+    u32x4 an[2][2], bn[2][TN];
+    {
+        constexpr int NTAP = (TAP + 1) % 9;
+        constexpr int nkh = NTAP / 3, nkw = NTAP % 3;
+        const int nchunk = TAP == 8 ? chunk + 1 : chunk;
+        const char* pb = patch + (nchunk & 1) * D_PATCH_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = c.p0[i] + nkh * c.PC + nkw;
+            const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);          // granule (s = 0) = fh, swizzled
+            an[i][0] = *reinterpret_cast<const u32x4*>(pb + a0);
+            an[i][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));        // granule 2 + fh
+        }
+        const char* wb = wring + slot_r * SLOT_BYTES + wn * 2048 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bn[0][j] = *reinterpret_cast<const u32x4*>(wb + j * 4096);
+            bn[1][j] = *reinterpret_cast<const u32x4*>(wb + j * 4096 + 1024);
+        }
+        slot_r = slot_r + 1 == D_SLOTS ? 0 : slot_r + 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (4b) second half (k16 step 1)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const vec b = __builtin_bit_cast(vec, bf[1][j]);
+        acc[0][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[0][1]), b, acc[0][j]);
+        acc[1][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[1][1]), b, acc[1][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[i][s] = an[i][s];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[s][j] = bn[s][j];
+    __builtin_amdgcn_sched_barrier(0);
+    // (5) own DMAs of step t + 2 have landed (2 ops per step are younger: steps t - 1 and t; + the patch ops if they were
+    //     issued in one of those two steps), then the block-wide rendezvous that makes every wave's pieces visible
+    if (TAP == D_PF_TAP || TAP == D_PF_TAP + 1) wait_vmcnt<4 + D_NI>();
+    else wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int BN, int TAP>
+__device__ __forceinline__ void d_chunk(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
+                                        int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
+                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
+    if constexpr (TAP < 9) {
+        d_kstep<T, BN, TAP>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+        d_chunk<T, BN, TAP + 1>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+    }
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
+    constexpr int TN = BN / 64;
+    constexpr int SLOT_BYTES = (BN / 32) * 2048;
+    static_assert(BN / 32 == 4, "one weight n-tile per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* patch = smem_raw;                                             // [2][256 px][64 B]
+    char* wring = smem_raw + 2 * D_PATCH_BYTES;                         // [D_SLOTS][BN/32][2 KiB]
+    int* mtab = reinterpret_cast<int*>(wring + D_SLOTS * SLOT_BYTES);   // [128] output pixel of tile row, [128] head-layout base
+    float* sstab = reinterpret_cast<float*>(mtab + 256);                // [BN] scale, [BN] shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fh = lane >> 5, frow = lane & 31;
+
+    if (p.stagger > 0 && (int)blockIdx.x < p.first_wave) {             // see conv_f32_v2.hip
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int slot = (hw >> 16) & 15;
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    int bid = blockIdx.x;
+    {
+        const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int sp = fdiv(bid, p.mg_tn, p.tiles_n);
+    const int n_tile = bid - sp * p.tiles_n;
+
+    DCtx<T, TN> c;
+    c.KT = p.KT;
+    c.PC = p.PC;
+    c.wsrc = p.wf + (size_t)(n_tile * (BN / 32) + wave) * p.KT * 1024 + lane * 8;
+    // ---- prologue: weight steps 0 and 1 leave at once (they need nothing but n_tile); steps 2 .. D_P-1 follow the patch,
+    //      so that the first wait can leave them in flight (one in-order counter)
+    auto issue_w = [&](int q) {
+        const int kq = q < p.KT ? q : p.KT - 1;
+        const unsigned short* src = c.wsrc + (size_t)kq * 1024;
+        char* dst = wring + q * SLOT_BYTES + wave * 2048;
+        glds16(src, dst);
+        glds16(src + 512, dst + 1024);
+    };
+    issue_w(0);
+    issue_w(1);
+    // folded BatchNorm scale / shift of the block's BN channels: by LDS-DMA too (4 bytes per lane; waves 0-1 scale, 2-3 shift).
+    // An ordinary load here would be awaited with vmcnt(0) — hipcc does not count a register load apart from pending DMAs
+    {
+        const int n = n_tile * BN + (wave & 1) * 64 + lane;
+        const int ncl = n < p.Cout ? n : p.Cout - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)((wave < 2 ? p.scale : p.shift) + ncl), (lptr_t)(sstab + wave * 64), 4, 0, 0);
+    }
+    // patch geometry (as conv_patch_h16, KS = 3, stride 1)
+    const int r_tile = fdiv(sp, p.mg_tw, p.tiles_w);
+    const int w_tile = sp - r_tile * p.tiles_w;
+    const int g0 = r_tile * p.TH, c0 = w_tile * p.TW;
+    const int g_last = (g0 + p.TH < p.rows_total ? g0 + p.TH : p.rows_total) - 1;
+    const int Hp = p.Hin + 2;
+    auto vrow = [&](int g) {
+        const int n = fdiv(g, p.mg_H, p.H);
+        return n * Hp + (g - n * p.H);
+    };
+    const int v0 = vrow(g0);
+    const int PR = vrow(g_last) + 3 - v0;
+    {
+        const int gs = (tid & 3) ^ ((tid >> 4) & 3);           // source granule of LDS granule (pixel (tid>>2) + 64 i, slot tid & 3)
+        const unsigned short* zp = reinterpret_cast<const unsigned short*>(g_zero_page) + gs * 8;
+#pragma unroll
+        for (int i = 0; i < D_NI; ++i) {
+            const int idx = (tid >> 2) + 64 * i;
+            const int pr = fdiv(idx, p.mg_PC, p.PC), pc = idx - pr * p.PC;
+            const int vv = v0 + pr;
+            const int n = fdiv(vv, p.mg_Hp, Hp), yy = vv - n * Hp;
+            const int hi = yy - 1, wi = c0 + pc - 1;
+            const bool ok = (pr < PR) & ((unsigned)hi < (unsigned)p.Hin) & ((unsigned)wi < (unsigned)p.Win);
+            const int pix = (n * p.Hin + hi) * p.Win + wi;
+            c.psrc[i] = ok ? p.x + (size_t)pix * p.x_ld + p.x_off + gs * 8 : zp;
+        }
+        char* dst = patch + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < D_NI; ++i) glds16(c.psrc[i], dst + i * 4096);
+    }
+#pragma unroll
+    for (int q = 2; q < D_P; ++q) issue_w(q);
+    // while those travel: fragment rows and the tile-row -> output-pixel tables of the epilogue
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pp = wm * 64 + i * 32 + frow;
+        const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
+        const int g = g0 + r;
+        const bool ok = (pp < p.TH * p.TW) & (g <= g_last) & (c0 + cc < p.W);
+        c.p0[i] = ok ? (vrow(g) - v0) * p.PC + cc : 0;
+    }
+    if (tid < 128) {
+        const int r = fdiv(tid, p.mg_TW, p.TW), cc = tid - r * p.TW;
+        const int g = g0 + r;
+        int m = -1, mh = 0;
+        if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
+            m = g * p.W + c0 + cc;
+            if (p.out_mode == YOLO_OUT_HEAD) mh = m + 2 * (m / (p.Ho * p.Wo)) * (p.Ho * p.Wo);
+        }
+        mtab[tid] = m;
+        mtab[128 + tid] = mh;
+    }
+    // weights of steps 0 and 1 and the patch of chunk 0 must have landed; steps 2 .. D_P-1 (the 2 (D_P - 2) youngest ops)
+    // stay in flight — the same count the loop keeps
+    wait_vmcnt<2 * (D_P - 2)>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 af[2][2], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = c.p0[i];
+        const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);
+        af[i][0] = *reinterpret_cast<const u32x4*>(patch + a0);
+        af[i][1] = *reinterpret_cast<const u32x4*>(patch + (a0 ^ 32));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bf[0][j] = *reinterpret_cast<const u32x4*>(wring + wn * 2048 + lane * 16 + j * 4096);
+        bf[1][j] = *reinterpret_cast<const u32x4*>(wring + wn * 2048 + lane * 16 + j * 4096 + 1024);
+    }
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int slot_w = D_P % D_SLOTS, slot_r = 1;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk)
+        d_chunk<T, BN, 0>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+
+    // ---------------------------------------------------------------------- epilogue (fp32 math)
+    wait_vmcnt<0>();                                                  // the clamped tail DMAs still write LDS
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
+    const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
+    float sc[TN], sh[TN];                                       // this lane's output channel of pass j: n_tile*BN + j*64 + wn*32 + frow
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const bool nv = n_tile * BN + j * 64 + wn * 32 + frow < p.Cout;
+        sc[j] = nv ? sstab[j * 64 + wn * 32 + frow] : 0.f;
+        sh[j] = nv ? sstab[BN + j * 64 + wn * 32 + frow] : 0.f;
+    }
+    constexpr int OLD = 68;
+    float* ost = reinterpret_cast<float*>(smem_raw);                  // [TN][128][68] fp32: both 64-channel passes at once
+    const bool vec_ok = (p.out_mode != YOLO_OUT_HEAD) && (p.Cout % 8 == 0);
+    bool saw_nan = false;
+    const int c8 = tid & 7;
+    int mrow[4];
+    u32x4 rr[TN][4];
+    if (vec_ok) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) mrow[it] = mtab[(tid >> 3) + 32 * it];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rr[j][it] = z;
+            }
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int n = n_tile * BN + j * 64 + c8 * 8;
+                    const int mc = mrow[it] < 0 ? 0 : mrow[it];
+                    const int ncl = n < p.Cout ? n : 0;
+                    rr[j][it] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.r_ld + p.r_off + ncl);
+                }
+        }
+    }
+    // the tables live behind the staging tile only for BN = 128 with 5 ring slots (73,728 B >= 69,632 B): checked on the host
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float* dst = ost + j * 128 * OLD + wn * 32 + frow;
+        YOLO_SWITCH_ACT(p.act,
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc[j] + sh[j]);
+                })
+    }
+    __syncthreads();
+    if (vec_ok) {
+        unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+        if (has_res) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(rr[jj][it]));   // awaited before the first store is issued
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_tile * BN + j * 64 + c8 * 8;
+            f32x4 va[4], vb[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = (tid >> 3) + 32 * it;
+                va[it] = *reinterpret_cast<const f32x4*>(ost + j * 128 * OLD + row * OLD + c8 * 8);
+                vb[it] = *reinterpret_cast<const f32x4*>(ost + j * 128 * OLD + row * OLD + c8 * 8 + 4);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = mrow[it];
+                if (m < 0 || n >= p.Cout) continue;
+                float v[8] = {va[it][0], va[it][1], va[it][2], va[it][3], vb[it][0], vb[it][1], vb[it][2], vb[it][3]};
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] & 0xffffu));
+                        v[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] >> 16));
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (nan_chk && (v[2 * e] != v[2 * e] || v[2 * e + 1] != v[2 * e + 1])) saw_nan = true;
+                    o[e] = (unsigned)HTraits<T>::from_f32(v[2 * e]) | ((unsigned)HTraits<T>::from_f32(v[2 * e + 1]) << 16);
+                }
+                if (p.out_mode == YOLO_OUT_NHWC) {
+                    *reinterpret_cast<u32x4*>(yo + (size_t)m * p.y_ld + p.y_off + n) = o;
+                } else {
+                    const int HoWo = p.Ho * p.Wo;
+                    const int img = m / HoWo;
+                    const int rem = m - img * HoWo;
+                    const int ho = rem / p.Wo;
+                    const int wo2 = rem - ho * p.Wo;
+                    const int W2 = 2 * p.Wo;
+                    unsigned short* d = yo + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo2) * p.y_ld + p.y_off + n;
+                    *reinterpret_cast<u32x4*>(d) = o;
+                    *reinterpret_cast<u32x4*>(d + p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + (size_t)W2 * p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + (size_t)(W2 + 1) * p.y_ld) = o;
+                }
+            }
+        }
+    } else {                                        // odd channel counts / heads: generic scalar path (3x3 layers never take it in YOLOv3)
+        const int HoWo = p.Ho * p.Wo;
+        for (int j = 0; j < TN; ++j)
+            for (int it = 0; it < 32; ++it) {
+                const int idx = tid + 256 * it;
+                const int row = idx >> 6, col = idx & 63;
+                const int m = mtab[row];
+                const int n = n_tile * BN + j * 64 + col;
+                if (m < 0 || n >= p.Cout) continue;
+                float v = ost[j * 128 * OLD + row * OLD + col];
+                if (has_res) v += HTraits<T>::to_f32(p.res[(size_t)m * p.r_ld + p.r_off + n]);
+                if (nan_chk && v != v) saw_nan = true;
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo2 = rem - ho * p.Wo;
+                if (p.out_mode == YOLO_OUT_HEAD) {
+                    const int head_a = n / p.nc5, head_k = n - head_a * p.nc5;
+                    reinterpret_cast<float*>(p.y)[((size_t)((img * 3 + head_a) * p.Ho + ho) * p.Wo + wo2) * p.nc5 + head_k] = v;
+                } else if (p.out_mode == YOLO_OUT_NHWC) {
+                    reinterpret_cast<unsigned short*>(p.y)[(size_t)m * p.y_ld + p.y_off + n] = HTraits<T>::from_f32(v);
+                } else {
+                    const int W2 = 2 * p.Wo;
+                    unsigned short* d = reinterpret_cast<unsigned short*>(p.y) + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo2) * p.y_ld + p.y_off + n;
+                    const unsigned short hv = HTraits<T>::from_f32(v);
+                    d[0] = hv; d[p.y_ld] = hv; d[(size_t)W2 * p.y_ld] = hv; d[(size_t)(W2 + 1) * p.y_ld] = hv;
+                }
+            }
+    }
+    if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
 }
 
 // fragment-order 16-bit weights: [n_tile32][kt][s(2)][lane(64)][e(8)], n = nt*32 + (lane&31),
@@ -678,6 +1166,7 @@ __global__ void pack_batch_h16(const PackBatchH b) {
 
 // ------------------------------------------------------------------------------ host side
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
+static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
 
 size_t h16_frag_elems(int cout, int cin, int ks) {
     const int cinp = round_up(cin, 32);
@@ -809,7 +1298,7 @@ static void fill_magics(ConvHArgs& a) {
     a.mg_tn = magic_of(a.tiles_n); a.mg_tw = magic_of(a.tiles_w); a.mg_Hp = magic_of(a.Hin + 2);
 }
 
-static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax) {
+static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th, int* tw, int* prmax, int patch_cap = H_PATCH_CAP) {
     if (ks == 1) { *th = 1; *tw = 128; *prmax = 1; return; }
     double best = -1;
     *th = 1; *tw = 1; *prmax = 3 + 2;
@@ -819,7 +1308,7 @@ static void pick_tile_h(int Hin, int Hout, int Wout, int ks, int stride, int* th
         while (TH >= 1) {
             const int cross = (TH + Hout - 1) / Hout;
             pr = stride * (TH - 1) + 3 + 2 * cross;
-            if (pr * (stride * (TW - 1) + 3) <= H_PATCH_CAP) break;
+            if (pr * (stride * (TW - 1) + 3) <= patch_cap) break;
             --TH;
         }
         if (TH < 1) continue;
@@ -845,10 +1334,37 @@ static int launch_h(ConvHArgs& a, hipStream_t s) {
     size_t patch_bytes = (size_t)(a.bufmask + 1) * a.patch_cap * H_PIX_BYTES;
     if (patch_bytes < 128 * 68 * sizeof(float)) patch_bytes = 128 * 68 * sizeof(float);
     a.mtab_off = (int)patch_bytes;
-    const size_t lds = patch_bytes + 128 * sizeof(int);
+    const size_t lds = patch_bytes + 256 * sizeof(int);
     if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, KS, STRIDE>), dim3(a.nblocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_patch_h16<T, KS, STRIDE, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16");
+}
+
+template <typename T>
+static int launch_dma(ConvHArgs& a, hipStream_t s) {
+    constexpr int BN = 128;
+    a.tiles_n = ceil_div(a.Cout, BN);
+    const int tiles_r = ceil_div(a.rows_total, a.TH);
+    a.nblocks = a.tiles_n * a.tiles_w * tiles_r;
+    fill_magics(a);
+    a.first_wave = 2 * 256;
+    const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
+    a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
+    a.bufmask = 1;
+    a.mtab_off = 2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048;
+    static_assert(2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048 >= 2 * 128 * 68 * (int)sizeof(float), "epilogue staging fits in front of the tables");
+    const size_t lds = (size_t)a.mtab_off + 256 * sizeof(int) + 2 * BN * sizeof(float);
+    static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_h16<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YOLO_ERR_LAUNCH, "conv3_dma_h16: cannot reserve %zu bytes of LDS", lds);
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv3_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
+    return check_launch("conv3_dma_h16");
 }
 
 template <typename T, int BN, int MASK>
@@ -862,7 +1378,7 @@ static int launch_cls(ConvHArgs& a, hipStream_t s) {
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
     a.bufmask = 1;
     a.mtab_off = 2 * a.patch_cap * H_PIX_BYTES;
-    const size_t lds = (size_t)a.mtab_off + 128 * sizeof(int);
+    const size_t lds = (size_t)a.mtab_off + 256 * sizeof(int);
     if constexpr (BN == 64) hipLaunchKernelGGL((conv_patch_h16_n64<T, 3, 1, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_patch_h16<T, 3, 1, BN, MASK>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_h16 (dgrad s2 class)");
@@ -942,12 +1458,27 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     const long long M = (long long)d->n * a.Ho * a.Wo;
     if (M > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "conv: N*H*W exceeds int32");
     int prmax = 1;
+    // tile ids (16-bit): 5 / 6 = conv_patch_h16 with 64 / 128 output channels per block, 8 = conv3_dma_h16 (3x3 stride 1)
+    const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048;
+    if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
+    const bool use_dma = dma_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma));
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
     } else {
         a.H = a.Ho; a.W = a.Wo; a.rows_total = d->n * a.Ho;
-        pick_tile_h(d->h, a.Ho, a.Wo, 3, d->stride, &a.TH, &a.TW, &prmax);
+        pick_tile_h(d->h, a.Ho, a.Wo, 3, d->stride, &a.TH, &a.TW, &prmax, use_dma ? D_PATCH_PIX : H_PATCH_CAP);
         a.PC = d->stride * (a.TW - 1) + 3;
+    }
+    if (use_dma) {
+        if (prmax * a.PC > D_PATCH_PIX) return fail(YOLO_ERR_UNSUPPORTED, "conv3_dma_h16: patch of %d pixels", prmax * a.PC);
+        a.patch_cap = D_PATCH_PIX;
+        a.tiles_w = ceil_div(a.W, a.TW);
+        a.nchunks = d->cin / 32;
+        a.KT = a.nchunks * 9;
+        a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
+        a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
+        if (d->dtype == YOLO_BF16) return launch_dma<__bf16>(a, s);
+        return launch_dma<_Float16>(a, s);
     }
     // Not rounded up to the staging granularity of 64 pixels (the stores are guarded): measured with per-block stamps, a CU
     // never held more than TWO of the 64-wide 3x3 blocks although registers and the occupancy API allow three — their

@@ -97,8 +97,9 @@ class GradBuckets:
     non-distributed reference run would have them per batch.
     """
 
-    def __init__(self, params_in_backward_order, dist, bucket_mb=25.0, device=None):
+    def __init__(self, params_in_backward_order, dist, bucket_mb=25.0, device=None, only_trainable=True):
         self.dist = dist
+        self.signature = None                 # ids of the member parameters, set by the train engine (rebuild when it changes)
         self.world = dist.get_world_size() if dist is not None else 1
         self.buckets = []                     # dict(buf, pending, total, work)
         self.slot = {}                        # id(param) -> (bucket index, offset, numel, shape)
@@ -106,7 +107,7 @@ class GradBuckets:
         cur, cur_n = [], 0
         groups = []
         for p in params_in_backward_order:
-            if not p.requires_grad:
+            if only_trainable and not p.requires_grad:
                 continue
             if cur and cur_n + p.numel() > limit:
                 groups.append(cur)
@@ -128,7 +129,20 @@ class GradBuckets:
         if dist is not None and dist.get_backend() == "nccl":
             self.use_avg = True
 
-    def begin(self):
+    def begin(self, params=()):
+        """Start of a backward. The gradient tensors handed to autograd are views into the buckets, and AccumulateGrad keeps
+        such a view as ``p.grad`` when the parameter had none. If a ``p.grad`` from an earlier backward is still alive
+        (``zero_grad(set_to_none=False)``, micro-batch accumulation) it IS the memory the kernels are about to overwrite, and
+        autograd would then add the bucket to itself: give such a parameter its own copy first, so ``p.grad += new`` adds two
+        different tensors like it does on one GPU."""
+        for p in params:
+            g = p.grad
+            if g is not None and id(p) in self.slot:
+                bi, off, n, _shape = self.slot[id(p)]
+                base = self.buckets[bi]["buf"]
+                lo = base.data_ptr() + off * 4
+                if g.device == base.device and lo <= g.data_ptr() < lo + n * 4:
+                    p.grad = g.clone()
         for b in self.buckets:
             b["pending"], b["work"] = b["total"], None
 

@@ -198,32 +198,38 @@ class PackedBlock:
         self.packs_conv = n != 0
         if stem_ok:
             self.stem_w = torch.empty(27 * cv.out_channels, dtype=torch.float32, device=device)   # [27][cout]
-        self.stamp = None
+        self.stamp = None                 # conv weight (data_ptr, version) the packed copy was made from
+        self.fold_stamp = None            # same for the tensors behind scale / shift; None = not folded
         self.folded = False
 
     @staticmethod
     def stamp_of(block):
-        ts = [block.conv.weight]
+        """(weight stamp, fold stamp): identity + version of the conv weight, and of the tensors the folded scale / shift
+        are made of. Versions only see writes PyTorch dispatched; tensors this library writes through raw pointers (the
+        BatchNorm running statistics in a train-mode forward, every parameter in a HIP-graph replay) are covered by
+        ``ModelState.mark_unfolded`` / ``invalidate`` instead."""
+        def st(ts):
+            return tuple((t.data_ptr(), t._version) for t in ts)
         if block.batch_norm_act:
             bn = block.batch_norm
-            ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        else:
-            ts.append(block.conv.bias)
-        return tuple((t.data_ptr(), t._version) for t in ts)
+            return st([block.conv.weight]), st([bn.weight, bn.bias, bn.running_mean, bn.running_var])
+        return st([block.conv.weight]), st([block.conv.bias])
 
-    def refresh(self, block, stream, fold_bn=True, conv_packed=False):
+    def refresh(self, block, stream, fold_bn=True, conv_packed=False, pack=True):
         """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold.
-        conv_packed: the conv weights were already written by a batched pack (ModelState.refresh_weights)."""
+        conv_packed: the conv weights were already written by a batched pack (ModelState.refresh_weights).
+        pack=False: the packed conv weights are current, only the folded scale / shift are refreshed."""
         lib = L.lib()
         cv = block.conv
         w = cv.weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
-        if self.packs_conv and not conv_packed:
-            L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
-                                          cv.kernel_size[0], self.code, stream), "yolo_pack_weights")
-        if self.stem_w is not None:
-            L.check(lib.yolo_stem_pack(w.data_ptr(), self.stem_w.data_ptr(), cv.out_channels, stream), "yolo_stem_pack")
+        if pack:
+            if self.packs_conv and not conv_packed:
+                L.check(lib.yolo_pack_weights(w.data_ptr(), self.w.data_ptr(), cv.out_channels, cv.in_channels,
+                                              cv.kernel_size[0], self.code, stream), "yolo_pack_weights")
+            if self.stem_w is not None:
+                L.check(lib.yolo_stem_pack(w.data_ptr(), self.stem_w.data_ptr(), cv.out_channels, stream), "yolo_stem_pack")
         self.folded = True
         if block.batch_norm_act and not fold_bn:
             self.folded = False
@@ -236,7 +242,8 @@ class PackedBlock:
             b = cv.bias.detach().float().contiguous()
             L.check(lib.yolo_bn_fold(0, b.data_ptr(), 0, 0, 0.0, self.scale.data_ptr(), self.shift.data_ptr(),
                                      cv.out_channels, stream), "yolo_bn_fold")
-        self.stamp = self.stamp_of(block)
+        self.stamp, fstamp = self.stamp_of(block)
+        self.fold_stamp = fstamp if self.folded else None
 
 
 class Plan:
@@ -323,6 +330,7 @@ class Plan:
             if op["pred"] is not None:
                 self.pred_ops[op["pred"]] = (i, op["Ho"], blk.conv.out_channels // 3)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.dropped = False
 
     def load_input(self, xin, stream):
         """NCHW fp32 input -> first activation: stem kernel, or the NHWC boundary copy."""
@@ -370,7 +378,9 @@ class ModelState:
         self._plans[key] = plan
         is_train = key[0] == "train"
         cap = self.max_train_plans if is_train else self.max_eval_plans
-        same = [k for k in self._plans if (k[0] == "train") == is_train]
+        # plans pinned by a captured HIP graph (GraphedTrainStep) hold pointers baked into the graph: never evicted,
+        # and they do not count against the cap
+        same = [k for k in self._plans if (k[0] == "train") == is_train and not getattr(self._plans[k], "pinned", False)]
         for k in same[:max(0, len(same) - cap)]:
             del self._plans[k]
         return plan
@@ -391,8 +401,12 @@ class ModelState:
         for per_dev in self._packed.values():
             for pk in per_dev.values():
                 pk.stamp = None
+                pk.fold_stamp = None
+                pk.folded = False
         if drop_plans:
             self._packed = weakref.WeakKeyDictionary()
+            for plan in self._plans.values():
+                plan.dropped = True              # a HIP graph holding raw pointers into this plan must not replay
             self._plans.clear()
 
     def packed(self, block, device, dtype="fp32"):
@@ -405,11 +419,14 @@ class ModelState:
         return pk
 
     def refresh_weights(self, blocks, device, stream, dtype="fp32", fold_bn=True):
-        stale = []
+        stale, refold = [], []
         for blk in blocks:
             pk = self.packed(blk, device, dtype)
-            if pk.stamp is None or pk.stamp != PackedBlock.stamp_of(blk) or (fold_bn and not pk.folded):
+            wst, fst = PackedBlock.stamp_of(blk)
+            if pk.stamp is None or pk.stamp != wst:
                 stale.append((blk, pk))
+            elif fold_bn and (not pk.folded or pk.fold_stamp != fst):
+                refold.append((blk, pk))             # weights current, scale / shift not (e.g. frozen conv, live running stats)
         # 16-bit: all stale conv weights in one launch per 48 layers (after an optimizer step that is every layer)
         batched = set()
         if dtype != "fp32" and len(stale) > 1:
@@ -425,6 +442,18 @@ class ModelState:
                 batched = set(keep)
         for blk, pk in stale:
             pk.refresh(blk, stream, fold_bn, conv_packed=id(pk) in batched)
+        for blk, pk in refold:
+            pk.refresh(blk, stream, True, pack=False)
+
+    def mark_unfolded(self, blocks):
+        """The BatchNorm running statistics of ``blocks`` were just written by a kernel (train-mode forward): every folded
+        scale / shift made from them, in any dtype, is out of date — whether or not the block was stale before."""
+        for blk in blocks:
+            per_dev = self._packed.get(blk)
+            if per_dev:
+                for pk in per_dev.values():
+                    pk.folded = False
+                    pk.fold_stamp = None
 
     # ------------------------------------------------------------------ inference forward
     def forward(self, model, x):

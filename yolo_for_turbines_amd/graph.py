@@ -47,6 +47,14 @@ class GraphedTrainStep:
                 for _ in range(max(1, warmup)):         # allocator warm-up, plan build, lazily created optimizer state
                     self._step_body()
             torch.cuda.current_stream(x.device).wait_stream(side)
+            # The graph bakes in raw pointers to the train plan's buffers (activations, statistics, workspaces, packed
+            # gradient weights). Own the plan: a strong reference keeps its memory alive, `pinned` exempts it from the
+            # model's LRU of plans (multi-scale training builds other sizes in between replays).
+            plans = [pl for k, pl in model._engine._plans.items() if k[0] == "train" and k[1] == x.shape[0] and k[2] == x.shape[2]]
+            if not plans:
+                raise RuntimeError("GraphedTrainStep: the warm-up steps left no train plan for this shape")
+            self._plan = plans[-1]
+            self._plan.pinned = True
             self.graph = torch.cuda.CUDAGraph()
             if self.zero_grad:
                 self.opt.zero_grad(set_to_none=True)
@@ -68,8 +76,19 @@ class GraphedTrainStep:
     def __call__(self, x, targets):
         if tuple(x.shape) != tuple(self.x.shape):
             raise ValueError(f"this graph was captured for input shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        if self._plan.dropped:
+            raise RuntimeError("GraphedTrainStep: the model dropped its plans after this graph was captured (model.to(...) / "
+                               ".float() / .half() move the parameters the graph points at): capture a new GraphedTrainStep")
         self.x.copy_(x, non_blocking=True)
         for dst, src in zip(self.targets, targets):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay rewrote every parameter and BatchNorm statistic without dispatching a torch op: version counters did
+        # not move, so every packed weight / BN fold cached for eval is stale by construction
+        self.model._engine.invalidate()
         return self.loss
+
+    def release(self):
+        """Give the pinned plan back to the model's LRU (its memory is freed once evicted and the graph is dropped)."""
+        self._plan.pinned = False
+        self.graph = None

@@ -82,6 +82,9 @@ class TrainPlan:
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.dgrad_w = {}                 # op index -> packed gradient-conv weights
         self.buckets = None               # dist.GradBuckets when data-parallel
+        self.gen = 0                      # bumped by every train-mode forward: a backward must see the buffers of ITS forward
+        self.pinned = False               # set by GraphedTrainStep: pointers into this plan are baked into a HIP graph
+        self.dropped = False              # set when the model dropped its plans (model.to(), ...)
 
     def view_ptr(self, v: TView):
         return self.ybuf[v.buf].data_ptr()
@@ -104,6 +107,7 @@ def _forward(state, model, plan: TrainPlan, x):
                                   code, plan.nan_flag.data_ptr(), stream), "yolo_nchw_to_nhwc")
     preds = [None] * prog.n_pred
     tracked = []                                         # num_batches_tracked counters: ONE foreach launch, not 72
+    stats_written, bn_blocks = [], []                    # running statistics written through raw pointers below
     for i, op in enumerate(prog.ops):
         blk, cv = op["block"], op["block"].conv
         pk = state.packed(blk, dev, plan.dtype)
@@ -136,6 +140,8 @@ def _forward(state, model, plan: TrainPlan, x):
                                   plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
         if track:
             tracked.append(bn.num_batches_tracked)
+            stats_written += [bn.running_mean, bn.running_var]
+            bn_blocks.append(blk)
         flag_ptr = plan.nan_flag.data_ptr() if (op["flags"] & L.FLAG_NANCHECK) else 0
         L.check(lib.yolo_bn_act_fwd(z.data_ptr(), cout, 0, st[0].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
                                     plan.view_ptr(rv) if rv is not None else 0, rv.ld if rv is not None else 0,
@@ -143,6 +149,11 @@ def _forward(state, model, plan: TrainPlan, x):
                                     cout, _act_code(blk), op["out_mode"], code, flag_ptr, stream), "yolo_bn_act_fwd")
     if tracked:
         torch._foreach_add_(tracked, 1)
+        # yolo_bn_stats updated running_mean / running_var in place behind PyTorch's back: bump their version counters
+        # (what an in-place torch op would have done) and drop every BN fold made from them — including the folds of
+        # blocks whose WEIGHTS were not stale (frozen backbone), which an eval forward would otherwise keep using
+        torch.autograd.graph.increment_version(stats_written)
+        state.mark_unfolded(bn_blocks)
     return preds
 
 
@@ -376,6 +387,8 @@ class YoloTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, holder, *params):
         state, model, plan, _plist = holder
+        plan.gen += 1
+        ctx.gen = plan.gen
         preds = _forward(state, model, plan, x)
         ctx.holder = holder
         return tuple(preds)
@@ -383,22 +396,29 @@ class YoloTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dpreds):
         state, model, plan, plist = ctx.holder
+        if plan.gen != ctx.gen:
+            raise RuntimeError("yolo_for_turbines_amd: a newer train-mode forward of the same (batch, size, dtype) has overwritten "
+                               "the activations this backward needs (one set of buffers per shape): call backward() before the "
+                               "next forward, or run the second forward under torch.no_grad() / model.eval()")
         need = {id(p): ctx.needs_input_grad[2 + j] for j, p in enumerate(plist)}
         with torch.cuda.device(plan.device):
             buckets = None
             if state.ddp is not None:
+                order = []
+                for op in reversed(plan.prog.ops):           # the order in which _backward produces gradients
+                    blk = op["block"]
+                    if blk.batch_norm_act:
+                        order += [blk.batch_norm.weight, blk.batch_norm.bias, blk.conv.weight]
+                    else:
+                        order += [blk.conv.bias, blk.conv.weight]
+                order = [p for p in order if need.get(id(p), False)]
+                sig = tuple(id(p) for p in order)
                 buckets = plan.buckets
-                if buckets is None:
+                if buckets is None or buckets.signature != sig:      # first backward, or the trainable set changed (unfreeze)
                     from .dist import GradBuckets
-                    order = []
-                    for op in reversed(plan.prog.ops):       # the order in which _backward produces gradients
-                        blk = op["block"]
-                        if blk.batch_norm_act:
-                            order += [blk.batch_norm.weight, blk.batch_norm.bias, blk.conv.weight]
-                        else:
-                            order += [blk.conv.bias, blk.conv.weight]
-                    buckets = plan.buckets = GradBuckets(order, state.ddp[0], state.ddp[1], plan.device)
-                buckets.begin()
+                    buckets = plan.buckets = GradBuckets(order, state.ddp[0], state.ddp[1], plan.device, only_trainable=False)
+                    buckets.signature = sig
+                buckets.begin(order)
             grads, _ = _backward(state, model, plan, list(dpreds), need, buckets=buckets)
             if buckets is not None:
                 buckets.finish()
