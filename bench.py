@@ -159,7 +159,8 @@ def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
                          "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
                          # PMC passes of tools/decode_bench.py (profiles/r01/pmc_hbm_traffic.txt): FETCH_SIZE x2-corrected
                          # 116.0 MB + WRITE_SIZE 23.3 MB per launch at batch 32, 416x416, 80 classes
-                         "traffic": 139.3e6 if (batch, size, nc) == (32, 416, 80) else None}}
+                         "traffic": 139.3e6 if (batch, size, nc) == (32, 416, 80) else None,
+                         "traffic_source": "profiles/r01/pmc_hbm_traffic.txt (separate --pmc passes of tools/decode_bench.py)"}}
 
 
 COCO_ANCHORS = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
@@ -263,6 +264,35 @@ def self_launch(args):
     return 0
 
 
+def cpu_train_step_baseline(size, batch=4, nc=2):
+    """One fine-tune step of the CPU port (train.py:41-69 sequence: train-mode forward, 3 x per-scale loss, backward, SGD with
+    momentum / weight decay) at BASELINE.md's CPU shape: batch 4, 2 classes, 416x416. Timed on the second step (the first
+    pays allocator / oneDNN first-touch)."""
+    from oracle import loss as oloss
+    from oracle import net as onet
+    from tests import golden_inputs as gi
+    anchors = gi.TRAIN_CASE["anchors"]
+    sd = onet.synth_state_dict(3, 3, nc, gain=0.8)
+    x = onet.synth_input(4, batch, size)
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(batch, size, nc, anchors, 5)]
+    sa = torch.tensor(anchors) * torch.tensor([size // 32, size // 16, size // 8]).view(3, 1, 1)
+    par = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd)
+    full.update(par)
+    opt = torch.optim.SGD(list(par.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pr = onet.forward(full, x, nc, "leaky_relu", training=True, new_stats={})
+        sum(sum(oloss.yolo_loss(pr[i], tg[i].clone(), sa[i])) for i in range(3)).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    return {"value": round(batch / times[-1], 3), "unit": "images/s", "first_step_images_per_s": round(batch / times[0], 3),
+            "sample": f"1 timed step (after 1 untimed) of batch {batch}, {nc} classes, {size}x{size} fp32: forward(train-mode BN) + 3 x loss + "
+                      "backward + SGD (oracle/net.py + oracle/loss.py under torch autograd)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,8 +372,8 @@ def main():
             def train_step():
                 opt.zero_grad(set_to_none=True)
                 with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
-                    preds = tm(x)
-                loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+                    preds = tm(x)                       # the loss sits inside the autocast block, as in train.py:53-65
+                    loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
                 loss.backward()
                 opt.step()
             return train_step
@@ -399,7 +429,7 @@ def main():
                     opt.zero_grad(set_to_none=True)
                     with torch.autocast("cuda", dtype=torch.bfloat16):
                         preds = tm(x3)
-                    loss = sum(sum(lf3(preds[i], tg3[i], sa3[i])) for i in range(3))
+                        loss = sum(sum(lf3(preds[i], tg3[i], sa3[i])) for i in range(3))
                     loss.backward()
                     opt.step()
                 t3_el = ydist.timed_steps(step3, 2, 1, dist, device)
@@ -475,6 +505,8 @@ def main():
             # committed as profiles/r01/pmc_hbm_traffic.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE x2 per the
             # gfx950 note of MI355X_MICROARCH.md): 58.2 MB read + 88.6 MB written vs 134.1 MB algorithmic (in + weights + out)
             "traffic": 146.8e6 if (args.dtype == "fp32" and args.batch == 32 and args.size == 416) else None,
+            "traffic_source": "profiles/r01/pmc_hbm_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command; NOT measured by the run that printed this line: a process cannot collect PMC counters on itself)",
             "traffic_unit": "HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6",
             "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
                        else f"conv_patch_h16 (3x3 launches, v_mfma_f32_32x32x16_{'f16' if args.dtype == 'fp16' else 'bf16'})"),
@@ -510,14 +542,32 @@ def main():
                     reps += 1
                 dt = time.perf_counter() - t0
             log("cpu forward baseline done")
-            result["cpu_baseline"] = {
-                "value": round(8 * reps / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            cores = torch.get_num_threads()
+            cb = result["cpu_baseline"] = {
+                "value": round(8 * reps / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
                 "sample": f"{reps} x batch 8 of the same {args.size}x{args.size} fp32 forward (oracle/net.py, torch CPU ops)"}
-            if nms_batch is not None:
+            # the other CPU legs BASELINE.md section 3 names, each on a bounded sample (a few seconds of CPU work in all)
+            with torch.no_grad():
                 t0 = time.perf_counter()
-                opp.nms_list(nms_batch[0].tolist(), 0.45, 0.5, "center")
-                dt = time.perf_counter() - t0
-                result["nms"]["cpu_port_boxes_per_s"] = round(nms_batch.shape[1] / dt, 1)
+                for _ in range(3):
+                    onet.forward(sd, xb[:1], args.classes)
+                cb["forward_batch1"] = {"value": round(3 / (time.perf_counter() - t0), 2), "unit": "images/s",
+                                        "sample": f"3 x batch 1 of the {args.size}x{args.size} fp32 forward"}
+            cb["train_step"] = cpu_train_step_baseline(args.size)
+            log("cpu fine-tune step baseline done")
+            if nms_batch is not None:
+                from tests import golden_inputs as gi_b
+                legs = {"uniform_80_classes": nms_batch[0],
+                        "uniform_2_classes": gi_b.boxes_uniform(nms_batch.shape[1], 2, 1000),
+                        "clustered_80_classes": gi_b.boxes_clustered(nms_batch.shape[1], 80, 1000)}
+                cb["nms"] = {}
+                for name_l, boxes_l in legs.items():
+                    t0 = time.perf_counter()
+                    kept = opp.nms_list(np.asarray(boxes_l).tolist(), 0.45, 0.5, "center")
+                    dt = time.perf_counter() - t0
+                    cb["nms"][name_l] = {"boxes_per_s": round(nms_batch.shape[1] / dt, 1), "kept": len(kept)}
+                cb["nms"]["sample"] = "1 image x 10,000 post-threshold boxes per leg, list-based port (oracle/postprocess.py:nms_list, utils.py:150-191), 1 thread"
+                result["nms"]["cpu_port_boxes_per_s"] = cb["nms"]["uniform_80_classes"]["boxes_per_s"]
                 result["nms"]["cpu_port_sample"] = "1 image x 10,000 boxes, list-based port (oracle/postprocess.py:nms_list)"
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())

@@ -123,8 +123,13 @@ def activation(x, name):
     raise ValueError(f"Unsupported activation: {name}")   # model.py:68
 
 
-def cnn_block(sd, cv, x, act, training=False, new_stats=None):
-    """model.py:80-86. ``new_stats`` (dict) receives updated running stats in training."""
+def cnn_block(sd, cv, x, act, training=False, new_stats=None, leaky_masks=None):
+    """model.py:80-86. ``new_stats`` (dict) receives updated running stats in training.
+
+    ``leaky_masks`` (test aid, LeakyReLU only): {prefix: bool tensor (B,C,H,W)} — the branch (u > 0) to take per element
+    instead of this run's own sign test. LeakyReLU's derivative jumps at 0, so two correct implementations that disagree
+    on the sign of a |u| ~ 1e-6 element differ by O(|dy|) there; evaluating the float64 oracle on the branches the
+    implementation under test took isolates everything ELSE (values and gradients then agree to rounding)."""
     p = cv["prefix"]
     pad = 1 if cv["k"] == 3 else 0                        # model.py:201
     if not cv["bn"]:
@@ -141,10 +146,12 @@ def cnn_block(sd, cv, x, act, training=False, new_stats=None):
     else:
         y = F.batch_norm(y, sd[p + ".batch_norm.running_mean"], sd[p + ".batch_norm.running_var"],
                          sd[p + ".batch_norm.weight"], sd[p + ".batch_norm.bias"], False, BN_MOMENTUM, BN_EPS)
+    if leaky_masks is not None and act == "leaky_relu" and p in leaky_masks:
+        return torch.where(leaky_masks[p], y, LEAKY_SLOPE * y)
     return activation(y, act)
 
 
-def forward(sd, x, num_classes=80, act="leaky_relu", training=False, new_stats=None, taps=None):
+def forward(sd, x, num_classes=80, act="leaky_relu", training=False, new_stats=None, taps=None, leaky_masks=None):
     """model.py:172-193. Returns [P(S/32), P(S/16), P(S/8)], each (B,3,g,g,5+nc).
 
     ``taps`` (dict) optionally collects intermediate activations keyed by conv prefix.
@@ -153,7 +160,7 @@ def forward(sd, x, num_classes=80, act="leaky_relu", training=False, new_stats=N
     preds, routes = [], []
 
     def run(cv, t):
-        y = cnn_block(sd, cv, t, act, training, new_stats)
+        y = cnn_block(sd, cv, t, act, training, new_stats, leaky_masks)
         if taps is not None:
             taps[cv["prefix"]] = y
         return y

@@ -382,13 +382,15 @@ def test_network_train_step_vs_golden(yt, golden, tag, act):
         got = got.reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy() if got.numel() > 4096 else got.numpy()
         scale = max(1e-7, float(np.abs(want).max()))
         err = float(np.abs(got - want).max())
-        # Elementwise bar. Mish is smooth: fp32 implementations agree to ~5e-5 of max|g| (measured against
-        # an fp64 run of the oracle: ours 5e-5, CPU fp32 2e-5). LeakyReLU's derivative jumps 0.1 -> 1 at
-        # u = 0, so any two fp32 implementations flip the branch on a few |u| < 1e-5 elements and single
-        # entries move by O(|dy|) (the CPU fp32 run is off by up to 6e-2 vs fp64 on some layers, ours on
-        # others); the per-parameter NORMS below stay within 5e-3 and are the real routing check.
-        tol = 1e-3 if act == "mish" else 2e-1
-        assert err <= tol * scale, f"{key}: max err {err} vs scale {scale}"
+        # Elementwise bar against the reference's fp32 run: Mish only (smooth: fp32 implementations agree to ~5e-5 of
+        # max|g|). LeakyReLU's derivative jumps 0.1 -> 1 at u = 0: the reference's own fp32 run takes a handful of
+        # branches differently from its float64 run (tests/golden/train_step_fp64.npz: single gradient entries of the early
+        # layers move by 1.5e-3 of max|g|), and another fp32 implementation takes a different handful. The LeakyReLU
+        # elementwise bar is therefore enforced against a float64 run ON THE SAME BRANCHES in
+        # test_network_train_step_leaky_vs_fp64_on_matched_branches (1e-3 of max|g|, every parameter); here the leaky case
+        # keeps the loss parts above and the 366 per-parameter gradient norms below.
+        if act == "mish":
+            assert err <= 1e-3 * scale, f"{key}: max err {err} vs scale {scale}"
     norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
     ref = g[f"{tag}/gradnorm_all"]
     assert norms.shape == ref.shape
@@ -398,12 +400,82 @@ def test_network_train_step_vs_golden(yt, golden, tag, act):
     opt.step()
     g0 = float(np.abs(g[f"{tag}/grad/layers.0.conv.weight"]).max())      # update = lr * (momentum-free first step)
     np.testing.assert_allclose(m.state_dict()["layers.0.conv.weight"].cpu().numpy(), g[f"{tag}/w0_after_sgd"], rtol=0,
-                               atol=1e-3 * tol * g0 + 2e-6)
+                               atol=1e-3 * (1e-3 if act == "mish" else 5e-2) * g0 + 2e-6)
     # the packed weights follow the optimizer: a second forward must see the updated parameters
     m.eval()
     with torch.no_grad():
         a = m(x)
     assert all(torch.isfinite(t).all() for t in a)
+
+
+def test_network_train_step_leaky_vs_fp64_on_matched_branches(yt, golden):
+    """The LeakyReLU fine-tune step against FLOAT64, elementwise, every parameter.
+
+    A LeakyReLU network's gradient is discontinuous in the pre-activations: an element with |u| ~ 1e-6 whose sign two
+    implementations disagree on changes its dz by 0.9 dy, and ONE such element in a 3x3x1024 map shifts every gradient
+    below it by ~1e-2 of its scale. So the float64 oracle is evaluated on the branches the GPU forward actually took
+    (`leaky_masks`, from the saved pre-activations) — then nothing discontinuous is left and the bar is the Mish bar,
+    1e-3 of max|g| — and, separately, the number of branches that differ from the float64 run's own is bounded: it
+    must be a handful out of 8.6 M, of the order of what the reference's fp32 run shows (train_step_fp64.npz vs
+    train_step.npz). Also reports the judge's metric |ours - fp64| vs |reference fp32 - fp64| on the golden samples."""
+    from oracle import loss as oloss
+    c = gi.TRAIN_CASE
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=c["nc"], activation="leaky_relu")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    sa = torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)
+    lf = yt.YOLOLoss()
+    preds = m(x.cuda())
+    sum(sum(lf(preds[i], tg[i].clone().cuda(), sa[i].cuda())) for i in range(3)).backward()
+    # branches taken by the GPU forward: u = (z - mean) * (gamma * invstd) + beta from the saved raw conv outputs
+    plan = [p for k, p in m._engine._plans.items() if k[0] == "train"][-1]
+    names = {id(mod): name for name, mod in m.named_modules()}
+    masks, B = {}, c["batch"]
+    for i, op in enumerate(plan.prog.ops):
+        if plan.z[i] is None:
+            continue
+        st, cout = plan.stats[i], op["block"].conv.out_channels
+        z = plan.z[i].view(B, op["Ho"], op["Wo"], cout)
+        u = (z - st[0]) * st[2] + st[3]
+        masks[names[id(op["block"])]] = (u > 0).permute(0, 3, 1, 2).cpu()
+    # float64 oracle: (a) its own branches (how many differ?), (b) the GPU's branches (gradients)
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    taps = {}
+    with torch.no_grad():
+        onet.forward(sd64, x.double(), c["nc"], "leaky_relu", training=True, new_stats={}, taps=taps)
+    differ = 0
+    for cv in onet.conv_list(3, c["nc"]):
+        if cv["bn"]:                                              # the tap is y = leaky(u): same sign as u
+            differ += int(((taps[cv["prefix"]] > 0) != masks[cv["prefix"]]).sum())
+    total = sum(int(v.numel()) for v in masks.values())
+    par = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd64)
+    full.update(par)
+    pr = onet.forward(full, x.double(), c["nc"], "leaky_relu", training=True, new_stats={}, leaky_masks=masks)
+    sum(sum(oloss.yolo_loss(pr[i], tg[i].clone().double(), sa[i].double())) for i in range(3)).backward()
+    worst, worst_key = 0.0, None
+    for k, p in m.named_parameters():
+        ref = par[k].grad
+        e = float((p.grad.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+        if e > worst:
+            worst, worst_key = e, k
+    g64, g32 = golden("train_step_fp64"), golden("train_step")
+    named = dict(m.named_parameters())
+    ratios = {}
+    for key in [k[len("leaky/grad/"):] for k in g64.files if k.startswith("leaky/grad/")]:
+        got = named[key].grad.cpu().double()
+        got = got.reshape(-1)[::gi.TRAIN_GRAD_STRIDE].numpy() if got.numel() > 4096 else got.numpy()
+        w64, w32 = g64[f"leaky/grad/{key}"], g32[f"leaky/grad/{key}"]
+        ratios[key] = float(np.abs(got - w64).max() / max(np.abs(w32 - w64).max(), 1e-30))
+    print(f"leaky train step: {differ} of {total} branches differ from the float64 run; on matched branches max elementwise "
+          f"gradient error {worst:.2e} of max|g| ({worst_key}); unmatched |ours-fp64| / |reference fp32-fp64| per golden sample: "
+          + ", ".join(f"{k.split('.conv')[0].split('.batch')[0]}={v:.1f}" for k, v in ratios.items()))
+    assert differ <= 64, differ                                   # a handful of |u| ~ 1e-6 elements out of ~8.6 M
+    assert worst <= 1e-3, (worst_key, worst)
 
 
 # ------------------------------------------------------------- multi-scale sizes (train.py:45-46)
@@ -501,11 +573,17 @@ def test_network_forward_16bit_vs_oracle(yt, dtype, tol):
         m._engine.compute_dtype = dtype
         out = m(x.cuda())
         m._engine.compute_dtype = None
-        with torch.autocast("cuda", dtype=torch.float16 if dtype == "fp16" else torch.bfloat16):
-            out_ac = m(x.cuda())
-    for o, oa, r, rb in zip(out, out_ac, ref, ref_bf16):
+        ac_dtype = torch.float16 if dtype == "fp16" else torch.bfloat16
+        with torch.autocast("cuda", dtype=ac_dtype):
+            out_ac = m(x.cuda())                                    # heads in the autocast dtype, like the reference's (model.py:145-148)
+            m._engine.autocast_heads = False
+            out_ac32 = m(x.cuda())
+            m._engine.autocast_heads = True
+    for o, oa, oa32, r, rb in zip(out, out_ac, out_ac32, ref, ref_bf16):
         assert o.dtype == torch.float32 and tuple(o.shape) == tuple(r.shape)
-        assert torch.equal(o, oa)                                   # autocast selects the same path
+        assert oa.dtype == ac_dtype and oa32.dtype == torch.float32
+        assert torch.equal(o, oa32)                                 # autocast selects the same kernels ...
+        assert torch.equal(o.to(ac_dtype), oa)                      # ... and hands the fp32 heads out rounded once
         scale = float(r.abs().max())
         err = float((o.cpu() - r).abs().max()) / scale
         err_cpu_bf16 = float((rb.float() - r).abs().max()) / scale
@@ -609,10 +687,11 @@ def test_network_train_step_16bit_vs_golden(yt, golden, dtype, cos_min, norm_tol
     grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
     sa = (torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)).cuda()
     lf = yt.YOLOLoss()
-    with torch.autocast("cuda", dtype=torch.float16 if dtype == "fp16" else torch.bfloat16):
+    ac_dtype = torch.float16 if dtype == "fp16" else torch.bfloat16
+    with torch.autocast("cuda", dtype=ac_dtype):                   # loss inside the autocast block, as train.py:53-65 has it
         preds = m(x)
-    assert all(p.dtype == torch.float32 for p in preds)
-    parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+        assert all(p.dtype == ac_dtype for p in preds)             # what the reference's forward returns under autocast
+        parts = torch.stack([torch.stack([t.float() for t in lf(preds[i], tg[i].clone(), sa[i])]) for i in range(3)])
     np.testing.assert_allclose(parts.detach().cpu().numpy(), g[f"{tag}/loss_parts"], rtol=norm_tol, atol=1e-3)
     parts.sum().backward()
     named = dict(m.named_parameters())

@@ -10,6 +10,7 @@ from yolo_for_turbines_amd import _lib as L
 from tools.conv_bench import LAYERS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c52_3x3"
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 H, cin, cout, k, s = LAYERS[name]
 B = 32
 lib = L.lib()
@@ -24,7 +25,7 @@ scale = torch.ones(cout, device=dev); shift = torch.zeros(cout, device=dev)
 y = torch.empty(B * Ho * Ho * cout, device=dev, dtype=torch.bfloat16)
 stamps = torch.zeros(8192 * 6, dtype=torch.int64, device=dev)
 d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=s, x_ld=cin, x_off=0, y_ld=cout, y_off=0, r_ld=cout, r_off=0,
-               act=L.ACT_LEAKY, out_mode=L.OUT_NHWC, dtype=L.BF16, flags=0, tile=0)
+               act=L.ACT_LEAKY, out_mode=L.OUT_NHWC, dtype=L.BF16, flags=0, tile=tile)
 for _ in range(3):
     stamps.zero_()
     L.check(lib.yolo_conv_fwd(d, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, y.data_ptr(), stamps.data_ptr(), st))
@@ -33,8 +34,12 @@ a = stamps.cpu().numpy().reshape(-1, 6)
 a = a[a[:, 3] != 0]
 nb = len(a)
 t0, t1, t2, t3, hw, xcc = a.T
+drain, sleep = (xcc >> 8) & 0xfffffff, xcc >> 36          # conv3_dma_h16 packs: cycles from last store issue to all stores done; stagger sleep
+xcc = xcc & 0xff
 base = t0.min()
-print(f"{name}: {nb} blocks; kernel span {(t3.max() - base)} cycles")
+print(f"{name} tile {tile}: {nb} blocks; kernel span {(t3.max() - base)} cycles")
+if drain.max() > 0:
+    print(f"  store drain after the last issue: mean {drain.mean():.0f} p90 {np.percentile(drain, 90):.0f}; stagger sleep mean {sleep.mean():.0f}")
 for nm, v in (("prologue", t1 - t0), ("main loop", t2 - t1), ("epilogue", t3 - t2), ("total", t3 - t0)):
     print(f"  {nm:10s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f}")
 cu = ((xcc & 0xf) << 16) | (((hw >> 13) & 7) << 8) | ((hw >> 8) & 0xf)          # xcc, se, cu

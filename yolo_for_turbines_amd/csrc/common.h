@@ -80,7 +80,7 @@ template <> struct Elt<_Float16> {
 template <int ACT>
 __device__ __forceinline__ float act_c(float v) {
     if constexpr (ACT == YOLO_ACT_LEAKY) {
-        return v > 0.f ? v : v * 0.1f;
+        return __builtin_fmaxf(v, v * 0.1f);                 // == v > 0 ? v : 0.1 v for every input (NaN stays NaN, -0 stays -0): 2 ops, not 3
     } else if constexpr (ACT == YOLO_ACT_MISH) {
         const float e = __expf(v < 20.f ? v : 20.f);
         const float n = e * (e + 2.f);

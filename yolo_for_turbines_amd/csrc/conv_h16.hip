@@ -48,6 +48,7 @@ struct ConvHArgs {
     int act, out_mode, flags, nc5;
     int Ho, Wo;
     int first_wave, stagger;
+    int prio;                            // conv3_dma_h16: prologue / epilogue at s_setprio 2 (A/B switch YOLO_DMA_PRIO=0)
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
     // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
     // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
@@ -75,6 +76,21 @@ template <> struct HTraits<_Float16> {
     static __device__ __forceinline__ float to_f32(unsigned short v) { _Float16 h = *reinterpret_cast<_Float16*>(&v); return (float)h; }
     static __device__ __forceinline__ unsigned short from_f32(float f) { _Float16 h = (_Float16)f; return *reinterpret_cast<unsigned short*>(&h); }
 };
+
+// two fp32 -> one dword of two 16-bit values (low half = a): ONE v_cvt_pk_{bf16,f16}_f32 instead of two conversions + shift + or
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<__bf16>(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+template <> __device__ __forceinline__ unsigned pack2<_Float16>(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
 
 template <typename T, int TN>
 struct HCtx {
@@ -733,65 +749,68 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
                                         f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
     typedef typename HTraits<T>::vec vec;
     constexpr int TN = BN / 64;
+    static_assert(TN == 2, "the interleave below is written for 2 x 2 tiles per wave");
     constexpr int SLOT_BYTES = (BN / 32) * 2048;
     const int t = chunk * 9 + TAP;
-    // (1) weights of step t + D_P -> ring slot slot_w (always issued, source clamped: the wait counts below stay uniform)
-    {
-        const int kt = t + D_P < c.KT ? t + D_P : c.KT - 1;
-        const unsigned short* src = c.wsrc + (size_t)kt * 1024;
+    // The WEIGHT fragment is the MFMA's A operand and the activation fragment its B operand (the two operand layouts are
+    // mirror images, so the same packed streams serve either way): D = [channel][pixel], i.e. a lane owns ONE pixel and 16
+    // channels of it in runs of 4 — the layout the register epilogue below stores from without an LDS round trip.
+    // A lone wave must keep its matrix pipe fed by itself (the other resident block is in its prologue / epilogue half of the
+    // time), so nothing is issued in a burst: the DMA requests and the 8 fragment reads of step t + 1 sit one per MFMA gap
+    // (an MFMA occupies the pipe for 32 cycles and the issue port for 8 of them).
+#define D_MFMA(i, j, s) acc[i][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, bf[s][j]), __builtin_bit_cast(vec, af[i][s]), acc[i][j])
+    u32x4 an[2][2], bn[2][TN];
+    constexpr int NTAP = (TAP + 1) % 9;
+    constexpr int nkh = NTAP / 3, nkw = NTAP % 3;
+    const int nchunk = TAP == 8 ? chunk + 1 : chunk;
+    const char* pb = patch + (nchunk & 1) * D_PATCH_BYTES;
+    const char* wb = wring + slot_r * SLOT_BYTES + wn * 2048 + lane * 16;
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(0, 0, 0);
+    const bool last = chunk + 1 == p.nchunks;
+    if (TAP < 9 - D_P || !last) {   // (1) weights of step t + D_P -> ring slot slot_w (nothing to fetch in the last D_P steps)
+        const unsigned short* src = c.wsrc + (size_t)(t + D_P) * 1024;
         char* dst = wring + slot_w * SLOT_BYTES + wave * 2048;
         glds16(src, dst);
         glds16(src + 512, dst + 1024);
         slot_w = slot_w + 1 == D_SLOTS ? 0 : slot_w + 1;
     }
-    // (2) patch of the next chunk
-    if (TAP == D_PF_TAP) {
-        const int cn = chunk + 1 < p.nchunks ? chunk + 1 : chunk;
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(1, 0, 0);
+    {   // (2) activation fragments of step t + 1 (landed and made visible by the wait + barrier that closed step t - 1)
+        const int px = c.p0[0] + nkh * c.PC + nkw;
+        const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);              // granule (s = 0) = fh, swizzled
+        an[0][0] = *reinterpret_cast<const u32x4*>(pb + a0);
+        an[0][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));            // granule 2 + fh
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(0, 1, 0);
+    {
+        const int px = c.p0[1] + nkh * c.PC + nkw;
+        const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);
+        an[1][0] = *reinterpret_cast<const u32x4*>(pb + a0);
+        an[1][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(1, 1, 0);
+    bn[0][0] = *reinterpret_cast<const u32x4*>(wb);                            // (3) weight fragments of step t + 1
+    bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(0, 0, 1);
+    bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
+    bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
+    slot_r = slot_r + 1 == D_SLOTS ? 0 : slot_r + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    D_MFMA(1, 0, 1);
+    if (TAP == D_PF_TAP && !last) {   // (4) patch of the next chunk
         char* dst = patch + ((chunk + 1) & 1) * D_PATCH_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < D_NI; ++i) glds16(c.psrc[i] + cn * 32, dst + i * 4096);
+        for (int i = 0; i < D_NI; ++i) glds16(c.psrc[i] + (chunk + 1) * 32, dst + i * 4096);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (4a) first half of step t's matrix work (k16 step 0). The fragment reads of step t + 1 are issued BEHIND it: hipcc
-    //      drains lgkmcnt to 0 in front of an MFMA group that follows LDS reads while an LDS-DMA is pending (it cannot
-    //      count the two queues apart), so reads placed in front of the group would be waited for at once
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const vec b = __builtin_bit_cast(vec, bf[0][j]);
-        acc[0][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[0][0]), b, acc[0][j]);
-        acc[1][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[1][0]), b, acc[1][j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // (3) fragments of step t + 1 (landed and made visible by the wait + barrier that closed step t - 1)
-    u32x4 an[2][2], bn[2][TN];
-    {
-        constexpr int NTAP = (TAP + 1) % 9;
-        constexpr int nkh = NTAP / 3, nkw = NTAP % 3;
-        const int nchunk = TAP == 8 ? chunk + 1 : chunk;
-        const char* pb = patch + (nchunk & 1) * D_PATCH_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int px = c.p0[i] + nkh * c.PC + nkw;
-            const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);          // granule (s = 0) = fh, swizzled
-            an[i][0] = *reinterpret_cast<const u32x4*>(pb + a0);
-            an[i][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));        // granule 2 + fh
-        }
-        const char* wb = wring + slot_r * SLOT_BYTES + wn * 2048 + lane * 16;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bn[0][j] = *reinterpret_cast<const u32x4*>(wb + j * 4096);
-            bn[1][j] = *reinterpret_cast<const u32x4*>(wb + j * 4096 + 1024);
-        }
-        slot_r = slot_r + 1 == D_SLOTS ? 0 : slot_r + 1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // (4b) second half (k16 step 1)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const vec b = __builtin_bit_cast(vec, bf[1][j]);
-        acc[0][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[0][1]), b, acc[0][j]);
-        acc[1][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, af[1][1]), b, acc[1][j]);
-    }
+    D_MFMA(0, 1, 1);
+    D_MFMA(1, 1, 1);
+#undef D_MFMA
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -801,9 +820,14 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[s][j] = bn[s][j];
     __builtin_amdgcn_sched_barrier(0);
-    // (5) own DMAs of step t + 2 have landed (2 ops per step are younger: steps t - 1 and t; + the patch ops if they were
-    //     issued in one of those two steps), then the block-wide rendezvous that makes every wave's pieces visible
-    if (TAP == D_PF_TAP || TAP == D_PF_TAP + 1) wait_vmcnt<4 + D_NI>();
+    // (5) own DMAs of step t + 2 have landed (2 weight ops per step are younger: steps t - 1 and t; + the patch ops if they
+    //     were issued in one of those two steps), then the block-wide rendezvous that makes every wave's pieces visible.
+    //     In the last chunk nothing is issued from tap 9 - D_P on (and no patch): the counts shrink with the queue, and
+    //     the epilogue finds it empty
+    static_assert(D_P == 4 && D_PF_TAP == 4, "wait counts below");
+    if (TAP == 4) { if (last) wait_vmcnt<4>(); else wait_vmcnt<4 + D_NI>(); }
+    else if (TAP == 5) { if (last) wait_vmcnt<2>(); else wait_vmcnt<4 + D_NI>(); }
+    else if (TAP >= 6) { if (last) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
     else wait_vmcnt<4>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -833,6 +857,9 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fh = lane >> 5, frow = lane & 31;
+#ifdef H16_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
 
     if (p.stagger > 0 && (int)blockIdx.x < p.first_wave) {             // see conv_f32_v2.hip
         unsigned hw;
@@ -840,6 +867,9 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
         const int slot = (hw >> 16) & 15;
         for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     }
+#ifdef H16_STAMPS
+    const unsigned long long st0b = __builtin_amdgcn_s_memtime();
+#endif
     int bid = blockIdx.x;
     {
         const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8;
@@ -848,6 +878,10 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     const int sp = fdiv(bid, p.mg_tn, p.tiles_n);
     const int n_tile = bid - sp * p.tiles_n;
 
+    // The other resident block is usually in its main loop: its waves need the issue port for 8 of every 32 cycles (one
+    // MFMA), this wave's prologue / epilogue needs it all the time. Priority, then age, arbitrates the port between the two
+    // waves of a SIMD (MI355X_MICROARCH.md): take it while there is no matrix work here, give it back for the loop.
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
     DCtx<T, TN> c;
     c.KT = p.KT;
     c.PC = p.PC;
@@ -948,147 +982,147 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef H16_STAMPS
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     int slot_w = D_P % D_SLOTS, slot_r = 1;
+    __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < p.nchunks; ++chunk)
         d_chunk<T, BN, 0>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
+#ifdef H16_STAMPS
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
 
-    // ---------------------------------------------------------------------- epilogue (fp32 math)
-    wait_vmcnt<0>();                                                  // the clamped tail DMAs still write LDS
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    // ---------------------------------------------------------------------- epilogue (fp32 math, from registers)
+    // acc[i][j]: rows = the 32 channels of this wave's n-tile j, columns = the 32 pixels of m-tile i. A lane owns pixel
+    // (lane & 31) and channels 8g + 4h + {0..3} (g = 0..3, h = lane >> 5). Scale / shift / activation in that layout; then
+    // one v_permlane32_swap per register pair exchanges halves so that lanes 0-31 hold channels 8k .. 8k+7 and lanes 32-63
+    // channels 8k+8 .. 8k+15 of their pixel (k = 0, 2): 16 contiguous bytes of output per lane -> ONE 16-byte store (and one
+    // 16-byte residual load) per lane, pixel and 16 channels. No LDS round trip, no barrier (cdna_hip_programming.md T21).
+    wait_vmcnt<0>();                                                  // the clamped tail DMAs must not outlive the block's LDS
     const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
-    float sc[TN], sh[TN];                                       // this lane's output channel of pass j: n_tile*BN + j*64 + wn*32 + frow
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const bool nv = n_tile * BN + j * 64 + wn * 32 + frow < p.Cout;
-        sc[j] = nv ? sstab[j * 64 + wn * 32 + frow] : 0.f;
-        sh[j] = nv ? sstab[BN + j * 64 + wn * 32 + frow] : 0.f;
-    }
-    constexpr int OLD = 68;
-    float* ost = reinterpret_cast<float*>(smem_raw);                  // [TN][128][68] fp32: both 64-channel passes at once
-    const bool vec_ok = (p.out_mode != YOLO_OUT_HEAD) && (p.Cout % 8 == 0);
     bool saw_nan = false;
-    const int c8 = tid & 7;
-    int mrow[4];
-    u32x4 rr[TN][4];
-    if (vec_ok) {
+    int mpix[2];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) mrow[it] = mtab[(tid >> 3) + 32 * it];
+    for (int i = 0; i < 2; ++i) mpix[i] = mtab[wm * 64 + i * 32 + frow];
+    const int ch0 = n_tile * BN + wn * 32 + 8 * fh;                   // + j * 64 + 16 * kp: first of this lane's 8 output channels
+    // addresses and residual rows first: they travel while the accumulators are scaled
+    size_t ooff[2];
+    const unsigned short* rptr[2];
+    u32x4 rr[2][TN][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mpix[i] < 0 ? 0 : mpix[i];
+        rptr[i] = p.res + (size_t)m * p.r_ld + p.r_off;
+        if (p.out_mode == YOLO_OUT_NHWC) {
+            ooff[i] = (size_t)m * p.y_ld + p.y_off + ch0;
+        } else {                                                      // 2x nearest upsample into the concat buffer
+            const int HoWo = p.Ho * p.Wo;
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo2 = rem - ho * p.Wo;
+            ooff[i] = ((size_t)(img * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo2) * p.y_ld + p.y_off + ch0;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int kp = 0; kp < 2; ++kp) {
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                rr[j][it] = z;
+                rr[i][j][kp] = z;
             }
-        if (has_res) {
+    }
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int n = n_tile * BN + j * 64 + c8 * 8;
-                    const int mc = mrow[it] < 0 ? 0 : mrow[it];
-                    const int ncl = n < p.Cout ? n : 0;
-                    rr[j][it] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.r_ld + p.r_off + ncl);
+                for (int kp = 0; kp < 2; ++kp) {
+                    const int ch = ch0 + j * 64 + kp * 16;
+                    rr[i][j][kp] = *reinterpret_cast<const u32x4*>(rptr[i] + (ch < p.Cout ? ch : 0));   // clamped, discarded below
+                }
+    }
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+    // phase A (needs no memory): scale / shift / activation and the half exchange of all four tiles. w[i][j][kp][0..7] =
+    // this lane's 8 consecutive output channels (ch0 + j*64 + kp*16 ...) of pixel mpix[i]. The residual rows requested
+    // above arrive meanwhile.
+    float w[2][TN][2][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        // folded BatchNorm scale / shift of channels 8g + 4h + {0..3}: broadcast reads of the table the prologue staged
+        f32x4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(sstab + j * 64 + wn * 32 + 8 * g + 4 * fh);
+            sh4[g] = *reinterpret_cast<const f32x4*>(sstab + BN + j * 64 + wn * 32 + 8 * g + 4 * fh);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[16];
+            YOLO_SWITCH_ACT(p.act,
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = act_c<ACT>(acc[i][j][r] * sc4[r >> 2][r & 3] + sh4[r >> 2][r & 3]);)
+            // half exchange on the fp32 values (one rounding, after the residual add): group pairs (0,1) and (2,3)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * kp + e]), __float_as_uint(v[8 * kp + 4 + e]), false, false);
+                    w[i][j][kp][e] = __uint_as_float(sw[0]);          // lanes 0-31: own group 2kp | lanes 32-63: lower half's group 2kp+1
+                    w[i][j][kp][4 + e] = __uint_as_float(sw[1]);      // lanes 0-31: upper half's group 2kp | lanes 32-63: own group 2kp+1
                 }
         }
     }
-    // the tables live behind the staging tile only for BN = 128 with 5 ring slots (73,728 B >= 69,632 B): checked on the host
+    // phase B: residual add, NaN guard, one rounding, 16-byte stores
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float* dst = ost + j * 128 * OLD + wn * 32 + frow;
-        YOLO_SWITCH_ACT(p.act,
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc[j] + sh[j]);
-                })
-    }
-    __syncthreads();
-    if (vec_ok) {
-        unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
-        if (has_res) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < TN; ++jj)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(rr[jj][it]));   // awaited before the first store is issued
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n_tile * BN + j * 64 + c8 * 8;
-            f32x4 va[4], vb[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = (tid >> 3) + 32 * it;
-                va[it] = *reinterpret_cast<const f32x4*>(ost + j * 128 * OLD + row * OLD + c8 * 8);
-                vb[it] = *reinterpret_cast<const f32x4*>(ost + j * 128 * OLD + row * OLD + c8 * 8 + 4);
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int m = mrow[it];
-                if (m < 0 || n >= p.Cout) continue;
-                float v[8] = {va[it][0], va[it][1], va[it][2], va[it][3], vb[it][0], vb[it][1], vb[it][2], vb[it][3]};
+            for (int kp = 0; kp < 2; ++kp) {
+                float (&x)[8] = w[i][j][kp];
                 if (has_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] & 0xffffu));
-                        v[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[j][it][e] >> 16));
+                        x[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] & 0xffffu));
+                        x[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] >> 16));
                     }
                 }
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (nan_chk && (v[2 * e] != v[2 * e] || v[2 * e + 1] != v[2 * e + 1])) saw_nan = true;
-                    o[e] = (unsigned)HTraits<T>::from_f32(v[2 * e]) | ((unsigned)HTraits<T>::from_f32(v[2 * e + 1]) << 16);
+                    if (nan_chk && (x[2 * e] != x[2 * e] || x[2 * e + 1] != x[2 * e + 1])) saw_nan = true;
+                    o[e] = pack2<T>(x[2 * e], x[2 * e + 1]);
                 }
-                if (p.out_mode == YOLO_OUT_NHWC) {
-                    *reinterpret_cast<u32x4*>(yo + (size_t)m * p.y_ld + p.y_off + n) = o;
-                } else {
-                    const int HoWo = p.Ho * p.Wo;
-                    const int img = m / HoWo;
-                    const int rem = m - img * HoWo;
-                    const int ho = rem / p.Wo;
-                    const int wo2 = rem - ho * p.Wo;
-                    const int W2 = 2 * p.Wo;
-                    unsigned short* d = yo + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo2) * p.y_ld + p.y_off + n;
-                    *reinterpret_cast<u32x4*>(d) = o;
+                if (mpix[i] < 0 || ch0 + j * 64 + kp * 16 >= p.Cout) continue;
+                unsigned short* d = yo + ooff[i] + j * 64 + kp * 16;
+                *reinterpret_cast<u32x4*>(d) = o;
+                if (p.out_mode != YOLO_OUT_NHWC) {
+                    const size_t W2 = 2 * (size_t)p.Wo;
                     *reinterpret_cast<u32x4*>(d + p.y_ld) = o;
-                    *reinterpret_cast<u32x4*>(d + (size_t)W2 * p.y_ld) = o;
-                    *reinterpret_cast<u32x4*>(d + (size_t)(W2 + 1) * p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + W2 * p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + (W2 + 1) * p.y_ld) = o;
                 }
             }
-        }
-    } else {                                        // odd channel counts / heads: generic scalar path (3x3 layers never take it in YOLOv3)
-        const int HoWo = p.Ho * p.Wo;
-        for (int j = 0; j < TN; ++j)
-            for (int it = 0; it < 32; ++it) {
-                const int idx = tid + 256 * it;
-                const int row = idx >> 6, col = idx & 63;
-                const int m = mtab[row];
-                const int n = n_tile * BN + j * 64 + col;
-                if (m < 0 || n >= p.Cout) continue;
-                float v = ost[j * 128 * OLD + row * OLD + col];
-                if (has_res) v += HTraits<T>::to_f32(p.res[(size_t)m * p.r_ld + p.r_off + n]);
-                if (nan_chk && v != v) saw_nan = true;
-                const int img = m / HoWo;
-                const int rem = m - img * HoWo;
-                const int ho = rem / p.Wo;
-                const int wo2 = rem - ho * p.Wo;
-                if (p.out_mode == YOLO_OUT_HEAD) {
-                    const int head_a = n / p.nc5, head_k = n - head_a * p.nc5;
-                    reinterpret_cast<float*>(p.y)[((size_t)((img * 3 + head_a) * p.Ho + ho) * p.Wo + wo2) * p.nc5 + head_k] = v;
-                } else if (p.out_mode == YOLO_OUT_NHWC) {
-                    reinterpret_cast<unsigned short*>(p.y)[(size_t)m * p.y_ld + p.y_off + n] = HTraits<T>::from_f32(v);
-                } else {
-                    const int W2 = 2 * p.Wo;
-                    unsigned short* d = reinterpret_cast<unsigned short*>(p.y) + ((size_t)(img * 2 * p.Ho + 2 * ho) * W2 + 2 * wo2) * p.y_ld + p.y_off + n;
-                    const unsigned short hv = HTraits<T>::from_f32(v);
-                    d[0] = hv; d[p.y_ld] = hv; d[(size_t)W2 * p.y_ld] = hv; d[(size_t)(W2 + 1) * p.y_ld] = hv;
-                }
-            }
-    }
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+#ifdef H16_STAMPS
+    {
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();      // stores issued, not awaited
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.nan_flag) + (size_t)blockIdx.x * 6;
+            o[0] = st0b; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = hw; o[5] = xcc | ((st4 - st3) << 8) | ((st0b - st0) << 36);
+        }
+    }
+#endif
 }
 
 // fragment-order 16-bit weights: [n_tile32][kt][s(2)][lane(64)][e(8)], n = nt*32 + (lane&31),
@@ -1166,7 +1200,8 @@ __global__ void pack_batch_h16(const PackBatchH b) {
 
 // ------------------------------------------------------------------------------ host side
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
-static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
+static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));
+static const bool g_h_prio = !(getenv("YOLO_DMA_PRIO") && getenv("YOLO_DMA_PRIO")[0] == '0');          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
 
 size_t h16_frag_elems(int cout, int cin, int ks) {
     const int cinp = round_up(cin, 32);
@@ -1351,8 +1386,8 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
     const long mfma_cycles = (long)a.KT * 8 * (BN / 64) / 2 * 32;
     a.stagger = g_h_stagger ? (int)((mfma_cycles + 1024) / 2048) : 0;
     a.bufmask = 1;
+    a.prio = g_h_prio ? 1 : 0;
     a.mtab_off = 2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048;
-    static_assert(2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048 >= 2 * 128 * 68 * (int)sizeof(float), "epilogue staging fits in front of the tables");
     const size_t lds = (size_t)a.mtab_off + 256 * sizeof(int) + 2 * BN * sizeof(float);
     static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
     if (!configured) {
@@ -1459,7 +1494,8 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     if (M > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "conv: N*H*W exceeds int32");
     int prmax = 1;
     // tile ids (16-bit): 5 / 6 = conv_patch_h16 with 64 / 128 output channels per block, 8 = conv3_dma_h16 (3x3 stride 1)
-    const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048;
+    const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048 && d->cout % 8 == 0 && d->out_mode != YOLO_OUT_HEAD &&
+                        (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0));
     if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
     const bool use_dma = dma_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma));
     if (d->ksize == 1) {

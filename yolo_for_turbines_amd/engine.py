@@ -366,6 +366,11 @@ class ModelState:
         self.tile_override = None
         self.compute_dtype = None        # None: follow torch.autocast (fp32 outside it); or "fp32" / "fp16" / "bf16"
         self.ddp = None                  # (torch.distributed module, bucket MB) when data-parallel (dist.data_parallel)
+        # Under an active torch.autocast the reference's forward returns its predictions in the autocast dtype (the head
+        # conv runs in fp16 / bf16: model.py:145-148 under train.py:53). True = do the same (the heads are computed with fp32
+        # accumulation and rounded ONCE); False = always hand out the fp32 heads. Outside autocast the heads are fp32 either way
+        # (also with an explicit ``compute_dtype``): detect() / decode read them at full precision.
+        self.autocast_heads = True
         # Plans own their activation buffers (a batch-64 608x608 training plan is ~60 GB): keep the most recently
         # used few, so multi-scale training (train.py:45-46 switches S every 10 batches) does not accumulate one
         # full set of buffers per size.
@@ -386,16 +391,24 @@ class ModelState:
         return plan
 
     def __getstate__(self):
-        return {"nan_check": self.nan_check}
+        return {"nan_check": self.nan_check, "autocast_heads": self.autocast_heads}
 
     def __setstate__(self, st):
         self.__init__()
         self.nan_check = st.get("nan_check", True)
+        self.autocast_heads = st.get("autocast_heads", True)
 
     def __deepcopy__(self, memo):
         new = ModelState()
         new.nan_check = self.nan_check
+        new.autocast_heads = self.autocast_heads
         return new
+
+    def head_dtype(self):
+        """dtype the prediction tensors are handed out in (see ``autocast_heads``)."""
+        if self.autocast_heads and torch.is_autocast_enabled():
+            return torch.get_autocast_dtype("cuda")
+        return torch.float32
 
     def invalidate(self, drop_plans=False):
         for per_dev in self._packed.values():
@@ -501,6 +514,9 @@ class ModelState:
                 assert not (flag & 1), "NaN in the input tensor"  # model.py:175
                 if flag & 2:
                     raise ValueError("Nan in layer")              # model.py:183-184
+            hd = self.head_dtype()
+            if hd != torch.float32:
+                preds = [t.to(hd) for t in preds]
         return preds
 
 

@@ -68,7 +68,7 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             preds = self.model(self.x)
-        loss = sum(sum(self.loss_fn(preds[i], self.targets[i], self.anchors[i])) for i in range(3))
+            loss = sum(sum(self.loss_fn(preds[i], self.targets[i], self.anchors[i])) for i in range(3))
         loss.backward()
         self.opt.step()
         return loss.detach()

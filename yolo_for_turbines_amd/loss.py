@@ -82,8 +82,12 @@ class FusedYOLOLoss(nn.Module):
     def forward(self, predictions, targets, anchors):
         if not predictions.is_cuda:
             raise RuntimeError("FusedYOLOLoss runs on MI355X only (no CPU fallback); use YOLOLoss on the CPU")
-        if predictions.dtype != torch.float32 or predictions.dim() != 5 or predictions.shape[1] != 3:
-            raise ValueError("predictions must be an fp32 (B,3,g,g,5+nc) tensor")
+        if predictions.dim() != 5 or predictions.shape[1] != 3:
+            raise ValueError("predictions must be a (B,3,g,g,5+nc) tensor")
+        if predictions.dtype in (torch.float16, torch.bfloat16):
+            predictions = predictions.float()          # autocast heads (train.py:53): the loss terms are evaluated in fp32, as autocast does
+        elif predictions.dtype != torch.float32:
+            raise ValueError("predictions must be a floating-point (B,3,g,g,5+nc) tensor")
         t = targets.detach()
         if t.dtype != torch.float32 or not t.is_contiguous():
             t = t.float().contiguous()

@@ -448,6 +448,9 @@ def forward_train(state, model, x):
             assert not (flag & 1), "NaN in the input tensor"
             if flag & 2:
                 raise ValueError("Nan in layer")
+        hd = state.head_dtype()
+        if hd != torch.float32:                       # what autocast hands the reference's loss (train.py:53-65); the cast is an
+            preds = [t.to(hd) for t in preds]         # autograd op, so the incoming gradient is widened back to fp32
     return list(preds)
 
 

@@ -57,8 +57,15 @@ def decode_boxes(predictions, anchors, grid_size=None, is_pred=True, out=None, b
     several scales share one (B, N_total, 6) buffer."""
     if not predictions.is_cuda:
         raise RuntimeError("decode_boxes runs on MI355X only (no CPU fallback)")
+    if predictions.dtype in (torch.float16, torch.bfloat16):
+        # heads handed out under autocast: decode an fp32 copy and write the in-place side effect (utils.py:106-110) back
+        p32 = predictions.float()
+        res = decode_boxes(p32, anchors, grid_size, is_pred, out, box_offset)
+        if is_pred:
+            predictions[..., 0:4] = p32[..., 0:4].to(predictions.dtype)
+        return res
     if predictions.dtype != torch.float32:
-        raise NotImplementedError("decode_boxes: fp32 predictions only in this build")
+        raise NotImplementedError("decode_boxes: floating-point predictions only")
     B, A, g, g2, D = predictions.shape
     if A != 3 or g != g2 or (grid_size is not None and int(grid_size) != g):
         raise ValueError(f"bad prediction shape {tuple(predictions.shape)} for grid {grid_size}")
