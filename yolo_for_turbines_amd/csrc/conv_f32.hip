@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 // ------------------------------------------------------------------------------ host side
 
 
-constexpr int kNumTiles = 8;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU); 8: 16-bit only (conv3_dma_h16)
+constexpr int kNumTiles = 9;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU); 8: 16-bit only (conv3_dma_h16)
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }
 
@@ -341,7 +341,7 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     a.tiles_n = 0;
     const bool smallc = a.Cin == 4;
     const int t = d->tile ? d->tile : pick_tile(d);
-    if (t == 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 8 is a 16-bit kernel (conv3_dma_h16)");
+    if (t >= 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tiles 8 and 9 are 16-bit kernels (conv3_dma_h16)");
     if (t >= 5) {
         if (!v2_eligible(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile %d needs stride 1 and cin %% 32 == 0", t);
         const float* wf = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize);

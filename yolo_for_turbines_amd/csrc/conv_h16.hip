@@ -735,6 +735,26 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// SPEED PROBE ONLY (tile 9, results are garbage): the same FLOPs per K step issued as v_mfma_f32_16x16x32 instead of
+// 32x32x16 — MI355X_MICROARCH.md "DVFS give-back" (7): where the chip holds its clock down under load, the 16x16x32 shape
+// sustained ~1.15x the FLOP/s at equal cycles. Two 16x16x32 (16 cycles each) per 32x32x16 (32 cycles), on 4-register slices.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <typename T, int S>
+__device__ __forceinline__ void probe16(const u32x4& a, const u32x4& b, f32x16& acc) {
+    typedef typename HTraits<T>::vec vec;
+    f32x4v c0 = {acc[8 * S + 0], acc[8 * S + 1], acc[8 * S + 2], acc[8 * S + 3]};
+    f32x4v c1 = {acc[8 * S + 4], acc[8 * S + 5], acc[8 * S + 6], acc[8 * S + 7]};
+    if constexpr (sizeof(T) == 2 && __is_same(T, __bf16)) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec, a), __builtin_bit_cast(vec, b), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec, a), __builtin_bit_cast(vec, b), c1, 0, 0, 0);
+    } else {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec, a), __builtin_bit_cast(vec, b), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec, a), __builtin_bit_cast(vec, b), c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[8 * S + e] = c0[e]; acc[8 * S + 4 + e] = c1[e]; }
+}
+
 template <typename T, int TN>
 struct DCtx {
     const unsigned short* wsrc;      // this wave's n-tile of the fragment stream (+ lane * 8)
@@ -743,7 +763,7 @@ struct DCtx {
     int KT, PC;
 };
 
-template <typename T, int BN, int TAP>
+template <typename T, int BN, int TAP, bool P16>
 __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
                                         int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
                                         f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
@@ -758,7 +778,9 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     // A lone wave must keep its matrix pipe fed by itself (the other resident block is in its prologue / epilogue half of the
     // time), so nothing is issued in a burst: the DMA requests and the 8 fragment reads of step t + 1 sit one per MFMA gap
     // (an MFMA occupies the pipe for 32 cycles and the issue port for 8 of them).
-#define D_MFMA(i, j, s) acc[i][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, bf[s][j]), __builtin_bit_cast(vec, af[i][s]), acc[i][j])
+#define D_MFMA(i, j, s) \
+    if constexpr (P16) probe16<T, s>(bf[s][j], af[i][s], acc[i][j]); \
+    else acc[i][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, bf[s][j]), __builtin_bit_cast(vec, af[i][s]), acc[i][j])
     u32x4 an[2][2], bn[2][TN];
     constexpr int NTAP = (TAP + 1) % 9;
     constexpr int nkh = NTAP / 3, nkw = NTAP % 3;
@@ -833,17 +855,17 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int BN, int TAP>
+template <typename T, int BN, int TAP, bool P16>
 __device__ __forceinline__ void d_chunk(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
                                         int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
                                         f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
     if constexpr (TAP < 9) {
-        d_kstep<T, BN, TAP>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
-        d_chunk<T, BN, TAP + 1>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+        d_kstep<T, BN, TAP, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+        d_chunk<T, BN, TAP + 1, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
     }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool P16 = false>
 __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     constexpr int TN = BN / 64;
     constexpr int SLOT_BYTES = (BN / 32) * 2048;
@@ -989,7 +1011,7 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     int slot_w = D_P % D_SLOTS, slot_r = 1;
     __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < p.nchunks; ++chunk)
-        d_chunk<T, BN, 0>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+        d_chunk<T, BN, 0, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
     if (p.prio) __builtin_amdgcn_s_setprio(2);
 #ifdef H16_STAMPS
     asm volatile("s_nop 0" ::: "memory");
@@ -1398,6 +1420,15 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
         }
         configured = true;
     }
+    if (a.cls_ph == 9) {                                    // tile 9: MFMA-shape speed probe (garbage results), bf16 only
+        static bool configured9 = false;
+        if (!configured9) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_h16<__bf16, BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            configured9 = true;
+        }
+        hipLaunchKernelGGL((conv3_dma_h16<__bf16, BN, true>), dim3(a.nblocks), dim3(256), lds, s, a);
+        return check_launch("conv3_dma_h16 (probe)");
+    }
     hipLaunchKernelGGL((conv3_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv3_dma_h16");
 }
@@ -1497,7 +1528,8 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048 && d->cout % 8 == 0 && d->out_mode != YOLO_OUT_HEAD &&
                         (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0));
     if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
-    const bool use_dma = dma_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma));
+    const bool use_dma = dma_ok && (d->tile == 8 || d->tile == 9 || (d->tile == 0 && g_h_dma));
+    a.cls_ph = d->tile;
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
     } else {

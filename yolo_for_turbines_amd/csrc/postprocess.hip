@@ -24,6 +24,7 @@
 #include <cstring>
 #include "common.h"
 #include <rocprim/rocprim.hpp>
+#include <cstdlib>
 
 namespace yolo {
 
@@ -379,6 +380,171 @@ __global__ __launch_bounds__(256) void nms_gather2_kernel(const float* __restric
     if ((q & 63) == 63 || q == nv - 1) blk_hi[(size_t)b * W + (q >> 6)] = c;
 }
 
+// ---- hand-written ordering for n <= 32,768 (replaces the two rocPRIM sorts above; their ~16 merge launches were more
+// than half of the batched NMS). Both orders are full sorts of UNIQUE 64-bit keys (the index / rank is part of the key):
+//   order 1: make_key (score descending, index ascending)            -> global rank r of every valid box
+//   order 2: class bucket | rank r | index                            -> class-major rows (a stable partition by class)
+// Each is done by two launches that use the whole chip: (A) 2,048-key chunks sorted in LDS by a bitonic network, eight
+// keys per thread and three strides per LDS round trip; (B) one thread per key adds up, over the other chunks of its
+// image, how many keys are smaller (binary searches, all chunks of a step in flight together) — that sum plus its
+// position in its own chunk IS its final position, so the merge is a scatter. No atomics; deterministic.
+constexpr int SC = 2048;                 // keys per chunk
+constexpr int SC_MAXCH = 16;             // chunks per image handled here (n <= 32,768)
+constexpr int SC_ROW = 80;               // 8 keys (64 B) + 16 B pad per LDS row: a lane's 8 contiguous keys never share banks with its neighbours'
+__device__ __forceinline__ int sc_addr(int i) { return (i >> 3) * SC_ROW + (i & 7) * 8; }
+
+template <int LG>            // 2^LG keys per thread, SC >> LG threads, LG strides per LDS round trip
+__device__ __forceinline__ void chunk_sort_lds(char* lds, int tid) {
+    constexpr int KPT = 1 << LG;
+    // fully unrolled: every shift, mask and LDS offset below is an immediate
+#pragma unroll
+    for (int m = 1; m <= 11; ++m) {                       // bitonic merges of length 2^m; the last one ascending
+#pragma unroll
+        for (int p = m - 1; p >= 0; p -= LG) {            // strides 2^p .. 2^(p-LG+1) in ONE round trip
+            const int lo = p >= LG - 1 ? p - (LG - 1) : 0;   // the thread's keys differ in bits lo .. lo+LG-1
+            const int base = ((tid >> lo) << (lo + LG)) | (tid & ((1 << lo) - 1));
+            unsigned long long r[KPT];
+#pragma unroll
+            for (int a = 0; a < KPT; ++a) r[a] = *reinterpret_cast<const unsigned long long*>(lds + sc_addr(base | (a << lo)));
+#pragma unroll
+            for (int sb = LG - 1; sb >= 0; --sb) {
+                if (sb > p - lo) continue;
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) {
+                    if (a & (1 << sb)) continue;
+                    const unsigned long long x = r[a], y = r[a | (1 << sb)];
+                    const bool up = (((base | (a << lo)) >> m) & 1) == 0;      // direction of the length-2^m run this pair sits in
+                    const bool sw = (x > y) == up;
+                    r[a] = sw ? y : x;
+                    r[a | (1 << sb)] = sw ? x : y;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < KPT; ++a) *reinterpret_cast<unsigned long long*>(lds + sc_addr(base | (a << lo))) = r[a];
+            __syncthreads();
+        }
+    }
+}
+
+// (A) grid (nch, B), 256 threads. PHASE 1: keys from the boxes. PHASE 2: keys from order 1 (sorted1[b][r], r < nvalid[b]).
+constexpr int SC_LG = 2;                 // chunk sort: 4 keys per thread, 512 threads (two waves per SIMD cover each other's LDS latency)
+constexpr int SC_THREADS = SC >> SC_LG;
+template <int PHASE>
+__global__ __launch_bounds__(SC_THREADS) void nms_chunksort_kernel(const float* __restrict__ boxes, const unsigned long long* __restrict__ sorted1,
+                                                            const int* __restrict__ nvalid, int n, double obj_thr,
+                                                            unsigned long long* __restrict__ chunked, int* __restrict__ chunk_valid) {
+    __shared__ __attribute__((aligned(16))) char lds[(SC / 8) * SC_ROW];
+    const int b = blockIdx.y, c = blockIdx.x, nch = gridDim.x, tid = threadIdx.x;
+    const int nv = PHASE == 2 ? nvalid[b] : 0;
+#pragma unroll
+    for (int e = 0; e < (1 << SC_LG); ++e) {
+        const int loc = e * SC_THREADS + tid, i = c * SC + loc;
+        unsigned long long key = ~0ull;
+        if (PHASE == 1) {
+            if (i < n) key = make_key(boxes[((size_t)b * n + i) * 6 + 4], i, obj_thr);
+        } else {
+            // class bucket (12 bits; 0xfff = not a candidate) | global rank (20) | original index (20): unique for every r
+            key = (0xfffull << 40) | ((unsigned long long)(unsigned)i << 20);
+            if (i < nv) {
+                const unsigned long long idx = sorted1[(size_t)b * n + i] & 0xffffffffull;
+                key = ((unsigned long long)class_bucket(boxes[((size_t)b * n + idx) * 6 + 5]) << 40) | ((unsigned long long)(unsigned)i << 20) | idx;
+            }
+        }
+        *reinterpret_cast<unsigned long long*>(lds + sc_addr(loc)) = key;
+    }
+    __syncthreads();
+    chunk_sort_lds<SC_LG>(lds, tid);
+    unsigned long long* out = chunked + ((size_t)b * nch + c) * SC;
+#pragma unroll
+    for (int e = 0; e < (1 << SC_LG); ++e) {
+        const int loc = e * SC_THREADS + tid;
+        const unsigned long long key = *reinterpret_cast<const unsigned long long*>(lds + sc_addr(loc));
+        out[loc] = key;
+        if (PHASE == 1 && key != ~0ull) {                 // candidates sort first: the last one reports the count (zeroed before)
+            const unsigned long long nxt = loc + 1 < SC ? *reinterpret_cast<const unsigned long long*>(lds + sc_addr(loc + 1)) : ~0ull;
+            if (nxt == ~0ull) chunk_valid[b * SC_MAXCH + c] = loc + 1;
+        }
+    }
+}
+
+// number of keys of a sorted chunk that are smaller than `key`, for up to SC_MAXCH chunks at once (one load per chunk and step in flight)
+template <int MAXC>       // MAXC >= nch - 1: slot k is chunk k (k < c) or k + 1 (the thread's own chunk is skipped)
+__device__ __forceinline__ int rank_in_other_chunks(const unsigned long long* __restrict__ img, int nch, int c, unsigned long long key) {
+    int pos[MAXC];
+    const unsigned long long* base[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        pos[k] = 0;
+        const int ck = k + (k >= c ? 1 : 0);
+        base[k] = img + (size_t)(ck < nch ? ck : 0) * SC;       // clamped: unconditional loads
+    }
+#pragma unroll 1
+    for (int step = SC / 2; step >= 1; step >>= 1) {
+        unsigned long long v[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) v[k] = base[k][pos[k] + step - 1];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) pos[k] += v[k] < key ? step : 0;
+    }
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        // positions are in [0, SC - 1]: the last element needs its own test
+        const bool live = k + (k >= c ? 1 : 0) < nch;
+        const int full = pos[k] + ((live && pos[k] == SC - 1 && base[k][SC - 1] < key) ? 1 : 0);
+        total += live ? full : 0;
+    }
+    return total;
+}
+
+// (B, order 1) grid (nch * 8, B), 256 threads: one key per thread. Writes sorted1[b][rank] for the candidates and nvalid[b].
+template <int MAXC>
+__global__ __launch_bounds__(256) void nms_merge1_kernel(const unsigned long long* __restrict__ chunked, const int* __restrict__ chunk_valid,
+                                                         int nch, int n, unsigned long long* __restrict__ sorted1, int* __restrict__ nvalid,
+                                                         int* __restrict__ slot) {
+    const int b = blockIdx.y, c = blockIdx.x >> 3, ploc = (blockIdx.x & 7) * 256 + threadIdx.x;
+    const unsigned long long* img = chunked + (size_t)b * nch * SC;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int nv = 0;
+        for (int k = 0; k < nch; ++k) nv += chunk_valid[b * SC_MAXCH + k];
+        nvalid[b] = nv;
+    }
+    if (c * SC + ploc < n) slot[(size_t)b * n + c * SC + ploc] = -1;     // kept boxes by global rank, -1 elsewhere (nms_place fills it)
+    const unsigned long long key = img[(size_t)c * SC + ploc];
+    if (key == ~0ull) return;
+    const int rank = ploc + rank_in_other_chunks<MAXC>(img, nch, c, key);
+    sorted1[(size_t)b * n + rank] = key;
+}
+
+// (B, order 2) same geometry; the destination row q also receives what nms_gather2_kernel wrote (box, index, rank, class range)
+template <int MAXC>
+__global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict__ boxes, const unsigned long long* __restrict__ chunked,
+                                                         const int* __restrict__ nvalid, int nch, int n, int W, int center,
+                                                         unsigned long long* __restrict__ sorted2, int* __restrict__ order,
+                                                         int* __restrict__ grank, SBox* __restrict__ sbox, int* __restrict__ blk_lo,
+                                                         int* __restrict__ blk_hi) {
+    const int b = blockIdx.y, c = blockIdx.x >> 3, ploc = (blockIdx.x & 7) * 256 + threadIdx.x;
+    const unsigned long long* img = chunked + (size_t)b * nch * SC;
+    const unsigned long long k = img[(size_t)c * SC + ploc];
+    const int cls = (int)(unsigned)((k >> 40) & 0xfffull);
+    if (cls == 0xfff) return;                                   // not a candidate (they all sort behind the candidates)
+    const int q = ploc + rank_in_other_chunks<MAXC>(img, nch, c, k);
+    const int nv = nvalid[b];
+    const int i = (int)(unsigned)(k & 0xfffffull);
+    sorted2[(size_t)b * n + q] = ((unsigned long long)b << 52) | k;
+    const float* s = boxes + ((size_t)b * n + i) * 6;
+    float x = s[0], y = s[1];
+    const float w = s[2], h = s[3];
+    if (center) { x = x - w / 2.0f; y = y - h / 2.0f; }            // utils.py:60-64
+    SBox o;
+    o.x1 = x; o.y1 = y; o.x2 = x + w; o.y2 = y + h; o.area = w * h; o.cls = s[5]; o.w = w; o.h = h;
+    sbox[(size_t)b * n + q] = o;
+    order[(size_t)b * n + q] = i;
+    grank[(size_t)b * n + q] = (int)(unsigned)((k >> 20) & 0xfffffull);
+    if ((q & 63) == 0) blk_lo[(size_t)b * W + (q >> 6)] = cls;
+    if ((q & 63) == 63 || q == nv - 1) blk_hi[(size_t)b * W + (q >> 6)] = cls;
+}
+
 // grid (S = 4, W, B), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
 __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
                                                              const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
@@ -675,9 +841,12 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
     if (tid == 0) keep_count[b] = *total;
 }
 
+static const bool g_nms_rocprim = getenv("YOLO_NMS_ROCPRIM") != nullptr;       // A/B switch: the library sorts instead of the chunk sort + rank merge
+
 struct NmsWs { int* nvalid; unsigned long long* row_any; int* order; SBox* sbox; unsigned long long* mask; size_t zero_bytes; size_t total;
                unsigned long long* keys_in; unsigned long long* keys_out; void* sort_tmp; size_t sort_tmp_bytes;
-               int* grank; int* blk_lo; int* blk_hi; unsigned long long* keptw; };
+               int* grank; int* blk_lo; int* blk_hi; unsigned long long* keptw; int* chunk_valid; unsigned long long* chunked;
+               unsigned long long* sorted2; };
 
 static size_t sort_tmp_bytes(int b, int n) {
     size_t bytes = 0;
@@ -697,7 +866,8 @@ static NmsWs carve(void* base, int b, int n) {
     w.nvalid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1));
     w.row_any = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
     w.keptw = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
-    w.zero_bytes = off;                                 // nvalid + row_any + keptw are zeroed by one memset per call
+    w.chunk_valid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * SC_MAXCH);
+    w.zero_bytes = off;                                 // nvalid + row_any + keptw + chunk_valid are zeroed by one memset per call
     w.order = (int*)take(sizeof(int) * (size_t)b * n);
     w.sbox = (SBox*)take(sizeof(SBox) * (size_t)b * n);
     w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)b * n * W);
@@ -708,6 +878,9 @@ static NmsWs carve(void* base, int b, int n) {
     w.grank = (int*)take(sizeof(int) * (size_t)b * n);
     w.blk_lo = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * W);
     w.blk_hi = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * W);
+    const bool own_sort = n <= SC * SC_MAXCH;
+    w.chunked = (unsigned long long*)take(own_sort ? sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * ceil_div(n > 0 ? n : 1, SC) * SC : 8);
+    w.sorted2 = (unsigned long long*)take(own_sort ? sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * (n > 0 ? n : 1) : 8);
     w.total = off;
     return w;
 }
@@ -795,6 +968,30 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         rc = check_launch("nms_gather");
         if (rc) return rc;
     } else if (sorted_keys) {                               // + class-sorted rows
+        int* slot = (int*)w.keys_in;                        // kept boxes by global rank, -1 elsewhere
+        if (n <= SC * SC_MAXCH && !g_nms_rocprim) {          // both orders by the chunk sort + rank merge kernels (4 launches)
+            const int nch = ceil_div(n, SC);
+            const dim3 ga(nch, b), gb(nch * 8, b);
+            hipLaunchKernelGGL(nms_chunksort_kernel<1>, ga, dim3(SC_THREADS), 0, st, boxes, (const unsigned long long*)nullptr, (const int*)nullptr, n,
+                               obj_threshold, w.chunked, w.chunk_valid);
+            if (nch <= 3) hipLaunchKernelGGL(nms_merge1_kernel<2>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
+            else if (nch <= 5) hipLaunchKernelGGL(nms_merge1_kernel<4>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
+            else if (nch <= 9) hipLaunchKernelGGL(nms_merge1_kernel<8>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
+            else hipLaunchKernelGGL(nms_merge1_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
+            rc = check_launch("nms order 1");
+            if (rc) return rc;
+            hipLaunchKernelGGL(nms_chunksort_kernel<2>, ga, dim3(SC_THREADS), 0, st, boxes, w.keys_out, w.nvalid, n, obj_threshold, w.chunked,
+                               w.chunk_valid);
+            // order 2 lands in a second array: order 1 (keys_out) is still being read by the chunk sort above
+            unsigned long long* sorted2 = w.sorted2;
+            if (nch <= 3) hipLaunchKernelGGL(nms_merge2_kernel<2>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
+            else if (nch <= 5) hipLaunchKernelGGL(nms_merge2_kernel<4>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
+            else if (nch <= 9) hipLaunchKernelGGL(nms_merge2_kernel<8>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
+            else hipLaunchKernelGGL(nms_merge2_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
+            rc = check_launch("nms order 2");
+            if (rc) return rc;
+            w.keys_out = sorted2;
+        } else {
         hipLaunchKernelGGL(nms_keys_kernel, gn, dim3(256), 0, st, boxes, n, obj_threshold, w.keys_in);
         rc = check_launch("nms_keys");
         if (rc) return rc;
@@ -807,12 +1004,12 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         tb = w.sort_tmp_bytes;
         if (rocprim::radix_sort_keys(w.sort_tmp, tb, w.keys_in, w.keys_out, (size_t)b * n, 40, 63, st) != hipSuccess)
             return fail(YOLO_ERR_LAUNCH, "nms: radix sort (class)");
-        int* slot = (int*)w.keys_in;                        // free again: kept boxes by global rank, -1 elsewhere
         if (hipMemsetAsync(slot, 0xff, sizeof(int) * (size_t)b * n, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
         hipLaunchKernelGGL(nms_gather2_kernel, gn, dim3(256), 0, st, boxes, w.keys_out, w.nvalid, n, W, center, w.order, w.grank,
                            w.sbox, w.blk_lo, w.blk_hi);
         rc = check_launch("nms_gather2");
         if (rc) return rc;
+        }
         // 4 blocks per row block: with many classes only the first 2-3 column blocks are in range and every further (empty)
         // block costs launch time (80 classes: 0.212 / 0.221 / 0.250 / 0.305 ms for 3 / 4 / 8 / 16), with 2 classes more
         // blocks help a little (1.16 / 1.12 / 1.05 / 1.02 ms)
