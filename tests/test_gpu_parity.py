@@ -290,6 +290,26 @@ def test_nms_class_sorted_path_awkward_classes(yt):
     np.testing.assert_array_equal(keep[:int(count)].cpu().numpy(), opp.nms_indices_c(batch[0], 0.0, -1.0, "corner"))
 
 
+@pytest.mark.parametrize("n,nc", [(2048, 80), (4096, 3), (4097, 80), (12288, 20), (22743, 80), (32768, 80), (33000, 80)])
+def test_nms_ordering_kernels_chunk_counts(yt, n, nc):
+    """The hand-written ordering (2,048-key chunks sorted in LDS + rank merge) for 1 .. 16 chunks per image, chunk
+    boundaries exactly at n, the largest grid of a forward (22,743 boxes at 608x608) and the first size that falls back
+    to the library sort: kept indices bit-exact against the C oracle, images with different numbers of candidates
+    (none, all, ties in the scores)."""
+    rng = np.random.Generator(np.random.PCG64(n + nc))
+    imgs = [gi.boxes_uniform(n, nc, 4000 + n), gi.boxes_clustered(n, nc, 4001 + n, jitter=0.15), gi.boxes_uniform(n, nc, 4002 + n)]
+    imgs[1][:, 4] = 0.5 + 0.5 * rng.random(n).astype(F32)          # every box is a candidate
+    imgs[1][::5, 4] = 0.875                                        # with many equal scores (index order decides)
+    imgs[2][:, 4] *= 0.4                                           # no candidate at all
+    batch = np.stack(imgs)
+    keep, count = yt.nms_indices(torch.from_numpy(batch).cuda(), 0.45, 0.5, "center")
+    assert int(count[2]) == 0
+    for b in range(2):
+        want = opp.nms_indices_c(batch[b], 0.45, 0.5, "center")
+        assert int(count[b]) == len(want)
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+
+
 def test_detect_pipeline_vs_oracle(yt):
     """forward -> decode (3 scales, reference concatenation order) -> NMS, against the oracle's
     decode of the oracle's forward; thresholds chosen so a few hundred boxes survive."""

@@ -49,6 +49,7 @@ struct Conv2Args {
     int act, out_mode, flags, nc5;
     int Ho, Wo;                 // real output dims (upsample / head addressing)
     int first_wave, stagger;    // blocks resident at launch; start delay (units of 64*127 cycles) per tg slot
+    int prio;                   // prologue / epilogue at s_setprio 2 (A/B switch YOLO_F32_PRIO=0)
 #ifdef V2_STAMPS
     unsigned long long* dbg;    // diagnostic build only (tools/v2_probe.hip): 4 s_memtime stamps per block
 #endif
@@ -176,6 +177,9 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
         for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
+    // The co-resident blocks are usually in their main loops and need the issue port for a fraction of every MFMA's 64
+    // cycles; this block's prologue / epilogue needs it continuously: take priority while there is no matrix work here.
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
     // XCD-aware, bijective block remap: blocks sharing a spatial tile (n tiles) and neighbouring
     // tiles land on the same XCD / L2 (speed only; any placement is correct).
     int bid = blockIdx.x;
@@ -241,6 +245,18 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
         c.wfrag[j] = p.wf + (size_t)nt * p.KT * 1024 + lane * 4;
     }
 
+    // folded BatchNorm scale / shift of this lane's output channel of pass j: requested here, with the first loads of the
+    // block (in the epilogue they were an exposed round trip per pass, in front of which every earlier store had to drain)
+    float sc[TN], sh[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_tile * BN + wn * (BN / 2) + j * 32 + frow;
+        const int ncl = n < p.Cout ? n : p.Cout - 1;           // clamped: unconditional loads
+        sc[j] = p.scale[ncl];
+        sh[j] = p.shift[ncl];
+        if (n >= p.Cout) { sc[j] = 0.f; sh[j] = 0.f; }
+    }
+
     f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -271,16 +287,20 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
     f32x4 af[2];
     af[0] = *reinterpret_cast<const f32x4*>(patch + c.a_off[0]);
     af[1] = *reinterpret_cast<const f32x4*>(patch + c.a_off[1]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));   // pinned here: not re-loaded in the epilogue
 
 #ifdef V2_STAMPS
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
     // chunks in pairs so the B double buffer keeps compile-time names (9 taps per chunk is odd)
+    __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < p.nchunks; chunk += 2) {
         v2_chunk<KS, TN, 0, false>(p, c, chunk, patch, bA, bB, stage, af, acc, tid);
         if (chunk + 1 < p.nchunks)
             v2_chunk<KS, TN, 0, (KS * KS) % 2 == 1>(p, c, chunk + 1, patch, bA, bB, stage, af, acc, tid);
     }
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
 
     // ---------------------------------------------------------------------- epilogue
 #ifdef V2_STAMPS
@@ -300,35 +320,65 @@ __global__ __launch_bounds__(256) void conv_patch_f32(const Conv2Args p) {
     const bool vec_ok = (p.out_mode != YOLO_OUT_HEAD) && (p.Cout % 4 == 0);
     bool saw_nan = false;
     __syncthreads();                                // every wave is done reading the patch
+    // residual rows of EVERY pass: requested before the accumulators go through LDS (they were loaded one by one, each
+    // behind an s_waitcnt vmcnt(0) that also waited for the stores in front of it: 8 exposed round trips per pass), and
+    // awaited before the first store is issued (one in-order counter for loads and stores)
+    f32x4 rr[TN][8];
+    int mrow[8];
+    if (vec_ok) {
+        const int c4 = tid & 15;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) mrow[it] = mtab[(tid >> 4) + 16 * it];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rr[j][it] = z;
+            }
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_tile * BN + (c4 >> 3) * (BN / 2) + j * 32 + (c4 & 7) * 4;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int mc = mrow[it] < 0 ? 0 : mrow[it];
+                    rr[j][it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.r_ld + p.r_off + (n < p.Cout ? n : 0));   // clamped, discarded below
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         {
-            const int n = n_tile * BN + wn * (BN / 2) + j * 32 + frow;
-            const bool nv = n < p.Cout;
-            const float sc = nv ? p.scale[n] : 0.f;
-            const float sh = nv ? p.shift[n] : 0.f;
             float* dst = ost + wn * 32 + frow;
             YOLO_SWITCH_ACT(p.act,
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {
                         const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc + sh);
+                        dst[row * OLD] = act_c<ACT>(acc[i][j][r] * sc[j] + sh[j]);
                     })
         }
         __syncthreads();
         if (vec_ok) {
+            f32x4 va[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)                              // all LDS reads first: one latency, not eight
+                va[it] = *reinterpret_cast<const f32x4*>(ost + ((tid >> 4) + 16 * it) * OLD + (tid & 15) * 4);
+            if (has_res && j == 0) {
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(rr[jj][it]));
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int idx = tid + 256 * it;
-                const int row = idx >> 4, c4 = idx & 15;
-                const int m = mtab[row];
+                const int c4 = tid & 15;
+                const int m = mrow[it];
                 const int n = n_tile * BN + (c4 >> 3) * (BN / 2) + j * 32 + (c4 & 7) * 4;
                 if (m < 0 || n >= p.Cout) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(ost + row * OLD + c4 * 4);
-                if (has_res) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.r_ld + p.r_off + n);
-                    v += rr;
-                }
+                f32x4 v = va[it];
+                if (has_res) v += rr[j][it];
                 if (nan_chk && (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3])) saw_nan = true;
                 if (p.out_mode == YOLO_OUT_NHWC) {
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.y_ld + p.y_off + n) = v;
@@ -418,6 +468,7 @@ __global__ void pack_weights_frag_f32(const float* __restrict__ w, float* __rest
 unsigned long long* g_v2_dbg = nullptr;
 #endif
 static const bool g_v2_stagger = !(getenv("YOLO_NO_STAGGER"));
+static const bool g_v2_prio = !(getenv("YOLO_F32_PRIO") && getenv("YOLO_F32_PRIO")[0] == '0');
 bool v2_eligible(const yolo_conv_desc* d) { return d->stride == 1 && d->cin % 32 == 0; }
 
 size_t v2_frag_elems(int cout, int cin, int ks) {
@@ -471,6 +522,7 @@ static int launch_v2(Conv2Args& a, hipStream_t s) {
     a.first_wave = (a.bufmask ? 2 : 3) * 256;
     const long mfma_cycles = (long)a.KT * 32 * (BN / 64) * 64;  // one block's matrix work per wave
     a.stagger = g_v2_stagger ? (int)((mfma_cycles + 64 * 127 / 2) / (64 * 127)) : 0;
+    a.prio = g_v2_prio ? 1 : 0;
     const size_t lds = (size_t)(a.bufmask + 1) * a.patch_cap * V2_LD * sizeof(float) + 128 * sizeof(int);   // >= 128*68*4 staging
     hipLaunchKernelGGL((conv_patch_f32<KS, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv_patch_f32");

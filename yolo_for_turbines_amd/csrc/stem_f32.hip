@@ -29,15 +29,14 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
                                                    void* __restrict__ yv, int N, int H, int W, int y_ld, int y_off, int act,
                                                    int dtype, int* nan_flag) {
     float* y = reinterpret_cast<float*>(yv);
-    // weights [27][COUT] in LDS: every lane reads the same address (broadcast, conflict-free).
-    // (Reading them through the scalar cache was tried first: hipcc hoists all 864 s_loads and
-    // spills 800 SGPRs.)
-    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = wt[i];
-    __syncthreads();
+    // Weights [27][COUT] come through the SCALAR cache as SGPR operands of the FMAs: 16 at a time (one s_load_dwordx16),
+    // inside loops that are NOT unrolled, so at most 48 of them are live (unrolled, hipcc hoists all 864 s_loads and spills
+    // 800 SGPRs). The earlier version broadcast them from LDS: one ds_read_b128 per four FMAs = 216 LDS reads per pixel made
+    // the kernel LDS-issue-bound (864 LDS cycles per wave against ~1,700 FMA cycles: 2.3 TB/s of output instead of ~5).
     const long long total = (long long)N * H * W;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
+    const long long p_raw = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = p_raw < total;
+    const long long p = live ? p_raw : total - 1;          // tail lanes recompute the last pixel (they take part in the store transpose)
     const int HW = H * W;
     const int n = (int)(p / HW);
     const int rem = (int)(p - (long long)n * HW);
@@ -60,17 +59,25 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
         in[1] = rok ? row[w] : 0.f;
         in[2] = (rok && w + 1 < W) ? row[w + 1] : 0.f;
         if (dh == 1) bad_in |= (in[1] != in[1]);          // centre tap: every input element exactly once
-        const float* wk = ws + t * 3 * COUT;
+        const float* wk = wt + t * 3 * COUT;              // wave-uniform address: scalar loads
+        // explicit channel pairs (co, co + 1): one v_pk_fma_f32 per pair with the two weights as an aligned SGPR pair (left to
+        // the vectoriser, odd pairings needed two s_mov per FMA and the scalar unit became the bottleneck)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2* wk2 = reinterpret_cast<const f32x2*>(wk);
 #pragma unroll
-        for (int dw = 0; dw < 3; ++dw)
+        for (int dw = 0; dw < 3; ++dw) {
+            const f32x2 inb = {in[dw], in[dw]};
 #pragma unroll
-            for (int q = 0; q < COUT / 4; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wk + dw * COUT + q * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q * 4 + e] = fmaf(in[dw], wv[e], acc[q * 4 + e]);
+            for (int k = 0; k < COUT / 2; ++k) {
+                const f32x2 w2 = wk2[dw * (COUT / 2) + k];
+                f32x2 a2 = {acc[2 * k], acc[2 * k + 1]};
+                a2 = __builtin_elementwise_fma(inb, w2, a2);
+                acc[2 * k] = a2[0];
+                acc[2 * k + 1] = a2[1];
             }
+        }
     }
-    if (bad_in) atomicOr(nan_flag, 1);                    // NaN in the INPUT tensor (model.py:175)
+    if (bad_in && live) atomicOr(nan_flag, 1);            // NaN in the INPUT tensor (model.py:175)
     bool bad = false;
     YOLO_SWITCH_ACT(act,
         _Pragma("unroll") for (int co = 0; co < COUT; ++co) {
@@ -78,7 +85,48 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
             bad |= (t != t);
             acc[co] = t;
         })
-    if (dtype == YOLO_F32) {
+    if (y_ld == COUT) {
+        // A wave's 64 pixels are ONE contiguous run of 64 * COUT elements in NHWC memory, but a lane owns a whole pixel
+        // (64 or 128 bytes): stored directly, every instruction writes 64 separate 16-byte pieces (measured 1.6 - 2.3 TB/s).
+        // Exchange through LDS so that instruction j writes bytes [1024 j, 1024 (j + 1)) of the run, 16 per lane.
+        __shared__ __attribute__((aligned(16))) char tr[4][64 * COUT * 4];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        char* my = tr[wave];
+        const int esz = dtype == YOLO_F32 ? 4 : 2;
+        const int row = COUT * esz, slots = row / 16;                 // bytes and 16-byte slots per pixel (8 or 4)
+        const long long wave_p0 = (long long)blockIdx.x * 256 + wave * 64;
+        const long long nvalid = total - wave_p0 < 64 ? total - wave_p0 : 64;
+        // slot q of pixel `lane` goes to slot q ^ ((lane >> 1) & (slots - 1)): spreads the 64 lanes' equal-q writes over the banks
+#pragma unroll
+        for (int q = 0; q < COUT * 4 / 16; ++q) {
+            if (q < slots) {
+                u32x4 v;
+                if (dtype == YOLO_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[q * 4 + e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (unsigned)stem_cvt(acc[q * 8 + 2 * e], dtype) | ((unsigned)stem_cvt(acc[q * 8 + 2 * e + 1], dtype) << 16);
+                }
+                *reinterpret_cast<u32x4*>(my + lane * row + ((q ^ ((lane >> 1) & (slots - 1))) << 4)) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's own LDS writes (no other wave touches this region)
+        char* gbase = reinterpret_cast<char*>(yv) + ((size_t)wave_p0 * COUT + y_off) * esz;
+#pragma unroll
+        for (int j = 0; j < COUT * 4 / 16; ++j) {
+            if (j < slots) {
+                const int o = j * 1024 + lane * 16;                   // byte offset inside the wave's run
+                const int px = o / row, sl = (o % row) >> 4;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(my + px * row + ((sl ^ ((px >> 1) & (slots - 1))) << 4));
+                if (px < nvalid) *reinterpret_cast<u32x4*>(gbase + o) = v;
+            }
+        }
+    } else if (dtype == YOLO_F32) {
+        if (!live) return;
         float* dst = y + (size_t)p * y_ld + y_off;
 #pragma unroll
         for (int co = 0; co < COUT; co += 4) {
@@ -86,6 +134,7 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
             *reinterpret_cast<f32x4*>(dst + co) = v;
         }
     } else {
+        if (!live) return;
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         unsigned short* dst = reinterpret_cast<unsigned short*>(yv) + (size_t)p * y_ld + y_off;
 #pragma unroll
@@ -97,7 +146,7 @@ __global__ __launch_bounds__(256) void stem3x3_f32(const float* __restrict__ x, 
             *reinterpret_cast<u32x4*>(dst + co) = o;
         }
     }
-    if (bad) atomicOr(nan_flag, 2);
+    if (bad && live) atomicOr(nan_flag, 2);
 }
 
 // OIHW (COUT,3,3,3) -> [27][COUT]
