@@ -763,15 +763,21 @@ struct DCtx {
     int KT, PC;
 };
 
-template <typename T, int BN, int TAP, bool P16>
+struct DRes {                       // residual rows of the epilogue, requested from inside the last chunk (see d_kstep)
+    const unsigned short* rptr[2];  // row of this lane's pixel in m-tile 0 / 1 (+ r_off), null-safe (pixel clamped)
+    int ch0;                        // first of this lane's 8 channels (+ j * 64 + kp * 16)
+    bool has_res;
+};
+
+template <typename T, int BN, int TAP, bool P16, bool LAST>
 __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
-                                        int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
-                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
+                                        const unsigned short*& wp, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
+                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh, const DRes& rs,
+                                        u32x4 (&rr)[2][BN / 64][2]) {
     typedef typename HTraits<T>::vec vec;
     constexpr int TN = BN / 64;
     static_assert(TN == 2, "the interleave below is written for 2 x 2 tiles per wave");
     constexpr int SLOT_BYTES = (BN / 32) * 2048;
-    const int t = chunk * 9 + TAP;
     // The WEIGHT fragment is the MFMA's A operand and the activation fragment its B operand (the two operand layouts are
     // mirror images, so the same packed streams serve either way): D = [channel][pixel], i.e. a lane owns ONE pixel and 16
     // channels of it in runs of 4 — the layout the register epilogue below stores from without an LDS round trip.
@@ -789,14 +795,19 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     const char* wb = wring + slot_r * SLOT_BYTES + wn * 2048 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(0, 0, 0);
-    const bool last = chunk + 1 == p.nchunks;
-    if (TAP < 9 - D_P || !last) {   // (1) weights of step t + D_P -> ring slot slot_w (nothing to fetch in the last D_P steps)
-        const unsigned short* src = c.wsrc + (size_t)(t + D_P) * 1024;
-        char* dst = wring + slot_w * SLOT_BYTES + wave * 2048;
-        glds16(src, dst);
-        glds16(src + 512, dst + 1024);
-        slot_w = slot_w + 1 == D_SLOTS ? 0 : slot_w + 1;
+    constexpr bool last = LAST;                             // the last chunk of a tile is its own instantiation
+    constexpr bool fetch = TAP < 9 - D_P || !last;          // nothing to fetch in the last D_P steps
+    if (LAST && TAP == 7 && rs.has_res) {                   // residual rows, first half (see the note at the wait below)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int ch = rs.ch0 + j * 64 + kp * 16;
+                rr[0][j][kp] = *reinterpret_cast<const u32x4*>(rs.rptr[0] + (ch < p.Cout ? ch : 0));   // clamped, discarded in the epilogue
+            }
     }
+    char* wdst = wring + slot_w * SLOT_BYTES + wave * 2048;
+    if (fetch) glds16(wp, wdst);                            // (1) weights of step t + D_P -> ring slot slot_w: first KiB here ...
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(1, 0, 0);
     {   // (2) activation fragments of step t + 1 (landed and made visible by the wait + barrier that closed step t - 1)
@@ -819,11 +830,25 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(0, 0, 1);
+    if (fetch) {                                            // ... second KiB four MFMAs later (a request costs ~60 cycles of issue, an
+        glds16(wp + 512, wdst + 1024);                      //     MFMA covers 32: two in one gap leave the matrix pipe idle)
+        wp += 1024;
+        slot_w = slot_w + 1 == D_SLOTS ? 0 : slot_w + 1;
+    }
     bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
     bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
     slot_r = slot_r + 1 == D_SLOTS ? 0 : slot_r + 1;
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(1, 0, 1);
+    if (LAST && TAP == 7 && rs.has_res) {                   // residual rows, second half
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int ch = rs.ch0 + j * 64 + kp * 16;
+                rr[1][j][kp] = *reinterpret_cast<const u32x4*>(rs.rptr[1] + (ch < p.Cout ? ch : 0));
+            }
+    }
     if (TAP == D_PF_TAP && !last) {   // (4) patch of the next chunk
         char* dst = patch + ((chunk + 1) & 1) * D_PATCH_BYTES + wave * 1024;
 #pragma unroll
@@ -846,22 +871,27 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     //     were issued in one of those two steps), then the block-wide rendezvous that makes every wave's pieces visible.
     //     In the last chunk nothing is issued from tap 9 - D_P on (and no patch): the counts shrink with the queue, and
     //     the epilogue finds it empty
+    //     From tap 6 of the last chunk the queue is empty: the residual rows of the epilogue are requested in tap 7 (ordinary
+    //     loads: with no DMA pending hipcc counts them normally) and have the last two K steps + the epilogue's arithmetic
+    //     to arrive; taps 7 and 8 wait for nothing.
     static_assert(D_P == 4 && D_PF_TAP == 4, "wait counts below");
     if (TAP == 4) { if (last) wait_vmcnt<4>(); else wait_vmcnt<4 + D_NI>(); }
     else if (TAP == 5) { if (last) wait_vmcnt<2>(); else wait_vmcnt<4 + D_NI>(); }
-    else if (TAP >= 6) { if (last) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
+    else if (TAP == 6) { if (last) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
+    else if (TAP >= 7) { if (!last) wait_vmcnt<4>(); }
     else wait_vmcnt<4>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int BN, int TAP, bool P16>
+template <typename T, int BN, int TAP, bool P16, bool LAST>
 __device__ __forceinline__ void d_chunk(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
-                                        int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
-                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh) {
+                                        const unsigned short*& wp, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
+                                        f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh, const DRes& rs,
+                                        u32x4 (&rr)[2][BN / 64][2]) {
     if constexpr (TAP < 9) {
-        d_kstep<T, BN, TAP, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
-        d_chunk<T, BN, TAP + 1, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+        d_kstep<T, BN, TAP, P16, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        d_chunk<T, BN, TAP + 1, P16, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
     }
 }
 
@@ -876,7 +906,8 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     int* mtab = reinterpret_cast<int*>(wring + D_SLOTS * SLOT_BYTES);   // [128] output pixel of tile row, [128] head-layout base
     float* sstab = reinterpret_cast<float*>(mtab + 256);                // [BN] scale, [BN] shift
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave id on the scalar unit: the DMA destinations need no VALU
     const int wm = wave >> 1, wn = wave & 1;
     const int fh = lane >> 5, frow = lane & 31;
 #ifdef H16_STAMPS
@@ -1009,9 +1040,31 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
     int slot_w = D_P % D_SLOTS, slot_r = 1;
+    const unsigned short* wp = c.wsrc + (size_t)D_P * 1024;         // weights of step D_P: advanced by one step per request
     __builtin_amdgcn_s_setprio(0);
-    for (int chunk = 0; chunk < p.nchunks; ++chunk)
-        d_chunk<T, BN, 0, P16>(p, c, chunk, patch, wring, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh);
+    // what the residual requests inside the last chunk need: this lane's output pixels and first channel
+    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
+    int mpix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mpix[i] = mtab[wm * 64 + i * 32 + frow];
+    DRes rs;
+    rs.ch0 = n_tile * BN + wn * 32 + 8 * fh;
+    rs.has_res = has_res;
+    u32x4 rr[2][TN][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rs.rptr[i] = p.res + (size_t)(mpix[i] < 0 ? 0 : mpix[i]) * p.r_ld + p.r_off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rr[i][j][kp] = z;
+            }
+    }
+    for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk)
+        d_chunk<T, BN, 0, P16, false>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+    d_chunk<T, BN, 0, P16, true>(p, c, p.nchunks - 1, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
     if (p.prio) __builtin_amdgcn_s_setprio(2);
 #ifdef H16_STAMPS
     asm volatile("s_nop 0" ::: "memory");
@@ -1024,22 +1077,13 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     // one v_permlane32_swap per register pair exchanges halves so that lanes 0-31 hold channels 8k .. 8k+7 and lanes 32-63
     // channels 8k+8 .. 8k+15 of their pixel (k = 0, 2): 16 contiguous bytes of output per lane -> ONE 16-byte store (and one
     // 16-byte residual load) per lane, pixel and 16 channels. No LDS round trip, no barrier (cdna_hip_programming.md T21).
-    wait_vmcnt<0>();                                                  // the clamped tail DMAs must not outlive the block's LDS
-    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
     bool saw_nan = false;
-    int mpix[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) mpix[i] = mtab[wm * 64 + i * 32 + frow];
-    const int ch0 = n_tile * BN + wn * 32 + 8 * fh;                   // + j * 64 + 16 * kp: first of this lane's 8 output channels
-    // addresses and residual rows first: they travel while the accumulators are scaled
+    const int ch0 = rs.ch0;                                           // + j * 64 + 16 * kp: first of this lane's 8 output channels
     size_t ooff[2];
-    const unsigned short* rptr[2];
-    u32x4 rr[2][TN][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mpix[i] < 0 ? 0 : mpix[i];
-        rptr[i] = p.res + (size_t)m * p.r_ld + p.r_off;
         if (p.out_mode == YOLO_OUT_NHWC) {
             ooff[i] = (size_t)m * p.y_ld + p.y_off + ch0;
         } else {                                                      // 2x nearest upsample into the concat buffer
@@ -1050,24 +1094,6 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
             const int wo2 = rem - ho * p.Wo;
             ooff[i] = ((size_t)(img * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo2) * p.y_ld + p.y_off + ch0;
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                rr[i][j][kp] = z;
-            }
-    }
-    if (has_res) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {
-                    const int ch = ch0 + j * 64 + kp * 16;
-                    rr[i][j][kp] = *reinterpret_cast<const u32x4*>(rptr[i] + (ch < p.Cout ? ch : 0));   // clamped, discarded below
-                }
     }
     unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
     // phase A (needs no memory): scale / shift / activation and the half exchange of all four tiles. w[i][j][kp][0..7] =
@@ -1223,7 +1249,8 @@ __global__ void pack_batch_h16(const PackBatchH b) {
 // ------------------------------------------------------------------------------ host side
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
 static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));
-static const bool g_h_prio = !(getenv("YOLO_DMA_PRIO") && getenv("YOLO_DMA_PRIO")[0] == '0');          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
+static const bool g_h_prio = !(getenv("YOLO_DMA_PRIO") && getenv("YOLO_DMA_PRIO")[0] == '0');
+static const bool g_h_dma_solo = getenv("YOLO_DMA_SOLO") != nullptr;          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
 
 size_t h16_frag_elems(int cout, int cin, int ks) {
     const int cinp = round_up(cin, 32);
@@ -1410,7 +1437,8 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
     a.bufmask = 1;
     a.prio = g_h_prio ? 1 : 0;
     a.mtab_off = 2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048;
-    const size_t lds = (size_t)a.mtab_off + 256 * sizeof(int) + 2 * BN * sizeof(float);
+    size_t lds = (size_t)a.mtab_off + 256 * sizeof(int) + 2 * BN * sizeof(float);
+    if (g_h_dma_solo) lds = 100 * 1024;                     // experiment: ONE block per CU (how fast is a block that has the SIMDs to itself?)
     static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_h16<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
