@@ -50,6 +50,8 @@ def host_cores():
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_H16_MFMA_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA peak (not the 2:1-sparsity marketing figure)
+TRAFFIC_F32_C52 = 146.8e6             # PMC: 58.2 MB read (x2-corrected) + 88.6 MB written, conv_patch_f32<3,64> 128->256 @52x52 B=32
+TRAFFIC_H16_C52 = None                # PMC: conv3_dma_h16 128->256 @52x52 B=32 (profiles/r02/pmc_hbm_traffic.txt)
 GFLOP_PER_IMAGE_416_NC80 = 65.864     # BASELINE.md §2 (75 convs, 2*Ho*Wo*Cout*Cin*k^2)
 
 
@@ -107,6 +109,47 @@ def per_launch_times(plan, reps, x):
         torch.cuda.synchronize()
         acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
     return acc / reps
+
+
+def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
+    """MFMA roofline of the 3x3 launches of one forward plan: algorithmic conv FLOPs / HIP-event launch durations."""
+    plan = next(iter(model._engine._plans.values()))
+    flops = conv_flops(plan)
+    with torch.no_grad():
+        times_ms = per_launch_times(plan, max(1, min(args.steps, 5)), x)
+    log(f"per-launch event timing done ({dtype})")
+    if args.per_layer:
+        for i, (op, t, f) in enumerate(zip(plan.prog.ops, times_ms, flops)):
+            cv = op["block"].conv
+            log(f"  op{i:2d} {cv.in_channels:4d}->{cv.out_channels:4d} k{op['k']} s{op['s']} {op['x'].H:3d}->{op['Ho']:3d} "
+                f"{t * 1e3:8.1f} us {f / t / 1e9:7.1f} TF")
+    is3 = np.array([op["k"] == 3 and i >= plan.first for i, op in enumerate(plan.prog.ops)])   # MFMA 3x3 launches
+    f3, t3 = float(np.sum(np.array(flops)[is3])), float(np.sum(times_ms[is3])) * 1e-3
+    fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
+    ach = f3 / t3 / 1e12
+    fp32 = dtype == "fp32"
+    peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_H16_MFMA_TFLOPS
+    at_cfg1 = args.batch == 32 and args.size == 416
+    out = {
+        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4),
+        # HBM bytes of one launch of the dominant kernel (128->256 3x3 at 52x52, batch 32) from the PMC passes committed under
+        # profiles/ (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md)
+        "traffic": (TRAFFIC_F32_C52 if fp32 else TRAFFIC_H16_C52) if at_cfg1 else None,
+        "traffic_source": (("profiles/r01/pmc_hbm_traffic.txt" if fp32 else "profiles/r02/pmc_hbm_traffic.txt") +
+                           " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/conv_bench.py on this kernel; NOT "
+                           "measured by the run that printed this line: a process cannot collect PMC counters on itself)"),
+        "traffic_unit": ("HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6" if fp32 else
+                         "HBM bytes per launch (PMC, conv3_dma_h16 128->256 @52x52); algorithmic 67.1e6"),
+        "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if fp32 else
+                   f"conv3_dma_h16 (stride-1 3x3) + conv_patch_h16 (stride-2 3x3), v_mfma_f32_32x32x16_{'f16' if dtype == 'fp16' else 'bf16'}"),
+        "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
+        "algorithmic_gflop_per_step": round(f3 / 1e9, 2),
+        "all_conv_launches": {"achieved": round(fall / tall / 1e12, 2), "launches_per_step": len(flops),
+                              "sum_kernel_ms": round(tall * 1e3, 3), "gflop_per_step": round(fall / 1e9, 2)},
+        "whole_step_tflops": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
+    }
+    return out
 
 
 def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
@@ -310,6 +353,7 @@ def main():
     ap.add_argument("--config5", action="store_true", help="(default on; kept for compatibility)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip BASELINE config 5 per-GPU shape: batch 16, 608x608 fp16 forward + decode + per-image NMS")
+    ap.add_argument("--no-h16", action="store_true", help="skip the secondary bf16 forward leg of the default (fp32) run")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip BASELINE config 3 shape: batch 64 multi-scale fine-tune steps (S cycles through 320..608)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed fine-tune steps (0 = skip the fwd+bwd leg)")
@@ -353,6 +397,18 @@ def main():
     with torch.no_grad():
         elapsed = ydist.timed_steps(lambda: model(x), args.steps, args.warmup, dist, device)
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    # ---- the same forward in bf16 (BASELINE configs[3-5] arithmetic; conv3_dma_h16 is its dominant kernel): a secondary
+    # line of the default run, never `value`
+    h16, m16, el16 = None, None, 0.0
+    if args.dtype == "fp32" and not args.no_h16:
+        m16 = seeded_model(yt, args.classes, device)
+        m16._engine.compute_dtype = "bf16"
+        with torch.no_grad():
+            el16 = ydist.timed_steps(lambda: m16(x), args.steps, args.warmup, dist, device)
+        h16 = {"metric": "images/sec at 416x416 (fwd)", "dtype": "bf16", "unit": "images/s",
+               "value": round(args.batch * world * args.steps / el16, 2), "ms_per_step": round(el16 / args.steps * 1e3, 4),
+               "note": "same weights, input and step count as the fp32 headline; 16-bit activations / weights, fp32 accumulation and heads"}
+        log(f"bf16 forward leg: {h16['value']} img/s")
     # ---------------------------------------------------------------- fwd+bwd leg (fine-tune step)
     train = None
     if args.train_steps > 0:
@@ -483,39 +539,10 @@ def main():
         result["config5"] = cfg5
     if rank == 0:
         # ------------------------------------------------------------ roofline (dominant kernel)
-        plan = next(iter(model._engine._plans.values()))
-        flops = conv_flops(plan)
-        with torch.no_grad():
-            times_ms = per_launch_times(plan, max(1, min(args.steps, 5)), x)
-        log("per-launch event timing done")
-        if args.per_layer:
-            for i, (op, t, f) in enumerate(zip(plan.prog.ops, times_ms, flops)):
-                cv = op["block"].conv
-                log(f"  op{i:2d} {cv.in_channels:4d}->{cv.out_channels:4d} k{op['k']} s{op['s']} {op['x'].H:3d}->{op['Ho']:3d} "
-                    f"{t * 1e3:8.1f} us {f / t / 1e9:7.1f} TF")
-        is3 = np.array([op["k"] == 3 and i >= plan.first for i, op in enumerate(plan.prog.ops)])   # MFMA 3x3 launches
-        f3, t3 = float(np.sum(np.array(flops)[is3])), float(np.sum(times_ms[is3])) * 1e-3
-        fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
-        ach = f3 / t3 / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_H16_MFMA_TFLOPS
-        result["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4),
-            # HBM bytes of one launch of the dominant kernel (conv_patch_f32<3,64>, 128->256 at 52x52, batch 32) from the PMC passes
-            # committed as profiles/r01/pmc_hbm_traffic.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE x2 per the
-            # gfx950 note of MI355X_MICROARCH.md): 58.2 MB read + 88.6 MB written vs 134.1 MB algorithmic (in + weights + out)
-            "traffic": 146.8e6 if (args.dtype == "fp32" and args.batch == 32 and args.size == 416) else None,
-            "traffic_source": "profiles/r01/pmc_hbm_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "command; NOT measured by the run that printed this line: a process cannot collect PMC counters on itself)",
-            "traffic_unit": "HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6",
-            "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
-                       else f"conv_patch_h16 (3x3 launches, v_mfma_f32_32x32x16_{'f16' if args.dtype == 'fp16' else 'bf16'})"),
-            "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
-            "algorithmic_gflop_per_step": round(f3 / 1e9, 2),
-            "all_conv_launches": {"achieved": round(fall / tall / 1e12, 2), "launches_per_step": len(flops),
-                                  "sum_kernel_ms": round(tall * 1e3, 3), "gflop_per_step": round(fall / 1e9, 2)},
-            "whole_step_tflops": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
-        }
+        result["roofline"] = conv_roofline(model, x, args.dtype, args, elapsed, gflop_img)
+        if h16 is not None:
+            h16["roofline"] = conv_roofline(m16, x, "bf16", args, el16, gflop_img)
+            result["forward_bf16"] = h16
         # ------------------------------------------------------------------ NMS secondary metric
         nms_batch = None
         if not args.no_nms:
