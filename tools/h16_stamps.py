@@ -61,3 +61,11 @@ for c in ids[:256]:
 print(f"  avg resident blocks per CU over its span: {np.mean(util):.2f}; start-after-previous-end gap: median {np.median(gaps):.0f}, mean {np.mean(gaps):.0f} cycles")
 first = np.sort(t0 - base)
 print(f"  block start times: first wave by {first[min(511, nb - 1)]} cycles; last start {first[-1]}; last end {(t3 - base).max()}")
+if os.environ.get("STAMPS_TIMELINE"):
+    for c in ids[:int(os.environ["STAMPS_TIMELINE"])]:
+        m = cu == c
+        order = np.argsort(t0[m])
+        b0 = t0[m].min()
+        print(f"  CU {c:#x}: start / loop / epilogue / end (k cycles since the CU's first block)")
+        for s_, a_, b_, e_ in zip(t0[m][order], t1[m][order], t2[m][order], t3[m][order]):
+            print(f"    {(s_ - b0) / 1e3:7.1f} {(a_ - b0) / 1e3:7.1f} {(b_ - b0) / 1e3:7.1f} {(e_ - b0) / 1e3:7.1f}   loop {(b_ - a_) / 1e3:5.1f}")

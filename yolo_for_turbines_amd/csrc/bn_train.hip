@@ -36,6 +36,8 @@ __device__ __forceinline__ void ldp(const float* __restrict__ p, float (&v)[VN])
 // CV = C/VN vector channels; thread t owns vector channel t % VC (VC = min(CV, 256)) and pixel lane
 // t / VC; a block covers every channel of its pixel range.
 struct RedGeom { int vc, lanes, passes; };
+constexpr int RED_MLP = 8;          // loads in flight per thread in the reductions
+constexpr int RED_RUN = 16;         // pixels per thread and block (the fp32 run in front of the fp64 tree)
 __device__ __forceinline__ RedGeom red_geom(int cv) {
     RedGeom g;
     g.vc = cv < 256 ? cv : 256;
@@ -44,23 +46,28 @@ __device__ __forceinline__ RedGeom red_geom(int cv) {
     return g;
 }
 
-// fixed-order reduction over the pixel lanes of a block through LDS, one channel component at a time
+// fixed-order reduction over the pixel lanes of a block through LDS: every thread parks its 2 VN fp64 sums (planar, so the
+// stores and the reads below are conflict-free), ONE barrier, then the vc * 2 VN outputs are spread over all 256 threads,
+// each adding its `lanes` terms in lane order. (One component at a time with only the lane-0 threads adding cost 2 VN
+// barrier pairs per block: a third of the kernel on the 20-40 MB layers.)
 template <int VN>
-__device__ __forceinline__ void block_reduce_store(double (&s)[VN], double (&q)[VN], const RedGeom& g, int t, int v, int lane,
-                                                   bool own, double* __restrict__ dst /* partial + (blk*c + vch*VN)*2 */) {
-    __shared__ double red[256][2];
+__device__ __forceinline__ void block_reduce_store(double (&s)[VN], double (&q)[VN], const RedGeom& g, int t,
+                                                   int vch0, int cv, double* __restrict__ dst /* partial + blk*c*2 */) {
+    __shared__ double red[2 * VN][256];
+    __syncthreads();                                    // the previous pass has finished reading
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
-        __syncthreads();
-        red[t][0] = s[e];
-        red[t][1] = q[e];
-        __syncthreads();
-        if (lane == 0 && own) {
-            double a = 0, b = 0;
-            for (int l = 0; l < g.lanes; ++l) { a += red[l * g.vc + v][0]; b += red[l * g.vc + v][1]; }
-            dst[e * 2] = a;
-            dst[e * 2 + 1] = b;
-        }
+        red[2 * e][t] = s[e];
+        red[2 * e + 1][t] = q[e];
+    }
+    __syncthreads();
+    const int outs = g.vc * 2 * VN;
+    for (int o = t; o < outs; o += 256) {
+        const int v = o % g.vc, k = o / g.vc;           // k = 2 e + {0: first sum, 1: second sum}
+        if (vch0 + v >= cv) continue;
+        double a = 0;
+        for (int l = 0; l < g.lanes; ++l) a += red[k][l * g.vc + v];
+        dst[((size_t)(vch0 + v) * VN + (k >> 1)) * 2 + (k & 1)] = a;
     }
 }
 
@@ -88,18 +95,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S
             int run = 0;
             const typename Elt<T>::S* zp = z + off + vch * VN;
             int p = p0 + lane;
-            // 4 independent 16-byte loads in flight per thread (one-at-a-time left the kernel at ~45 % of
-            // the achievable HBM rate: latency-bound, not bandwidth-bound)
-            for (; p + 3 * g.lanes < p1; p += 4 * g.lanes) {
-                float x[4][VN];
+            // RED_MLP independent 16-byte loads in flight per thread (one-at-a-time left the kernel at ~45 % of the achievable
+            // HBM rate, four at ~2.7 TB/s with the 1-2 blocks per CU of these grids: latency-bound, not bandwidth-bound)
+            for (; p + (RED_MLP - 1) * g.lanes < p1; p += RED_MLP * g.lanes) {
+                float x[RED_MLP][VN];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * ld, x[u]);
+                for (int u = 0; u < RED_MLP; ++u) Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * ld, x[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < RED_MLP; ++u)
 #pragma unroll
                     for (int e = 0; e < VN; ++e) { fs[e] += x[u][e]; fq[e] += x[u][e] * x[u][e]; }
                 if constexpr (LONG) {                    // only huge inputs: flush fp32 runs into fp64 (costs 4*VN VGPRs)
-                    run += 4;
+                    run += RED_MLP;
                     if (run >= 64) {
 #pragma unroll
                         for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
@@ -116,30 +123,46 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const typename Elt<T>::S
 #pragma unroll
             for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
         }
-        block_reduce_store<VN>(s, q, g, t, v, lane, vch < cv, partial + ((size_t)blockIdx.x * c + vch * VN) * 2);
+        block_reduce_store<VN>(s, q, g, t, pass * g.vc, cv, partial + (size_t)blockIdx.x * c * 2);
     }
 }
 
-// Fixed-order reduction of partial[nblk][c][2] for the finalize kernels: a block handles 16 channels
-// with 16 lanes each; lane l sums blocks l, l+16, ... (independent loads, pipelined), then lanes are
-// added in order 0..15 through LDS. (One thread per channel walking 1024 partials took ~65 us.)
+// Fixed-order reduction of partial[nblk][c][2] for the finalize kernels: a block handles FIN_CH channels with
+// 256 / FIN_CH lanes each; lane l sums blocks l, l + lanes, ... (independent 16-byte loads, pipelined), then the lanes are
+// added in order through LDS. (One thread per channel walking 1024 partials took ~65 us; 16 channels x 16 lanes per block
+// left a c = 256 layer on 16 CUs with ~40 dependent additions per thread: 12 us for 2.8 MB.)
+constexpr int FIN_CH = 4;
+constexpr int FIN_LANES = 256 / FIN_CH;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nblk, int c, int* ch_out,
                                                 double* s_out, double* q_out) {
-    __shared__ double red[16][16][2];
-    const int lc = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + lc;
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int lc = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
+    const int ch = blockIdx.x * FIN_CH + lc;
     double s = 0, q = 0;
-    if (ch < c)
-        for (int b = lane; b < nblk; b += 16) {
-            s += partial[((size_t)b * c + ch) * 2];
-            q += partial[((size_t)b * c + ch) * 2 + 1];
+    if (ch < c) {
+        const double* src = partial + (size_t)ch * 2;
+        const size_t step = (size_t)c * 2;
+        int b = lane;
+        for (; b + 3 * FIN_LANES < nblk; b += 4 * FIN_LANES) {     // four loads in flight (hipcc leaves the plain loop at one
+            f64x2 v[4];                                            // load + s_waitcnt vmcnt(0) per iteration); same adding order
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f64x2*>(src + (size_t)(b + u * FIN_LANES) * step);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u][0]; q += v[u][1]; }
         }
+        for (; b < nblk; b += FIN_LANES) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(src + (size_t)b * step);
+            s += v[0];
+            q += v[1];
+        }
+    }
     red[lane][lc][0] = s;
     red[lane][lc][1] = q;
     __syncthreads();
     if (lane != 0 || ch >= c) return false;
     s = 0; q = 0;
-    for (int l = 0; l < 16; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }
+    for (int l = 0; l < FIN_LANES; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }
     *ch_out = ch; *s_out = s; *q_out = q;
     return true;
 }
@@ -264,21 +287,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* 
             const typename Elt<T>::S* dp = dy + dy_off + vch * VN;
             const typename Elt<T>::S* zp = z + z_off + vch * VN;
             int p = p0 + lane;
-            for (; p + g.lanes < p1; p += 2 * g.lanes) {          // 4 loads in flight (2 pixels x {dy, z})
-                float d0[VN], d1[VN], x0[VN], x1[VN];
-                Vec16<T>::ld(dp + (size_t)p * dy_ld, d0);
-                Vec16<T>::ld(dp + (size_t)(p + g.lanes) * dy_ld, d1);
+            constexpr int NP = RED_MLP / 2;                       // RED_MLP loads in flight (NP pixels x {dy, z})
+            for (; p + (NP - 1) * g.lanes < p1; p += NP * g.lanes) {
+                float d[NP][VN], x[NP][VN];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) Vec16<T>::ld(dp + (size_t)(p + u * g.lanes) * dy_ld, d[u]);
                 if (mean) {
-                    Vec16<T>::ld(zp + (size_t)p * z_ld, x0);
-                    Vec16<T>::ld(zp + (size_t)(p + g.lanes) * z_ld, x1);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * z_ld, x[u]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
+                    for (int u = 0; u < NP; ++u)
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) x[u][e] = 0.f;
                 }
-                accum(d0, x0);
-                accum(d1, x1);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) accum(d[u], x[u]);
                 if constexpr (LONG) {
-                    run += 2;
+                    run += NP;
                     if (run >= 64) {
 #pragma unroll
                         for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
@@ -299,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const typename Elt<T>::S* 
 #pragma unroll
             for (int e = 0; e < VN; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
         }
-        block_reduce_store<VN>(s, q, g, t, v, lane, vch < cv, partial + ((size_t)blockIdx.x * c + vch * VN) * 2);
+        block_reduce_store<VN>(s, q, g, t, pass * g.vc, cv, partial + (size_t)blockIdx.x * c * 2);
     }
 }
 
@@ -380,13 +406,13 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const typename Elt<
     }
 }
 
-// Blocks of the reductions: each thread accumulates a short fp32 run (~32 pixels) before the fp64 tree, so the
+// Blocks of the reductions: each thread accumulates a short fp32 run (RED_RUN pixels) before the fp64 tree, so the
 // kernels need no per-thread fp64 state (that cost 3 of 8 waves/SIMD); `*long_run` selects the variant with
 // in-loop fp64 flushes for inputs so large that the block cap makes the runs long.
 static int red_blocks(int m, int c, int vn, int* pix_per_block, bool* long_run) {
     const int cv = c / vn;
     const int lanes = 256 / (cv < 256 ? cv : 256);
-    int ppb = 32 * lanes;
+    int ppb = RED_RUN * lanes;
     int nblk = (m + ppb - 1) / ppb;
     if (nblk > 4096) nblk = 4096;
     if (nblk < 1) nblk = 1;
@@ -431,7 +457,7 @@ int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gam
         else hipLaunchKernelGGL((bn_stats_partial<T, false>), dim3(nblk), dim3(256), 0, s, (const Elt<T>::S*)z, m, c, ld, off, ppb, (double*)workspace));
     int rc = check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, (const double*)workspace, nblk, m, c, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, s, (const double*)workspace, nblk, m, c, momentum,
                        eps, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
     return check_launch("bn_stats_finalize");
 }
@@ -477,7 +503,7 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
                                     (const Elt<T>::S*)z, z_ld, z_off, gamma ? mean : nullptr, invstd, scale, shift, m, c, ppb, part)));
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
     rc = check_launch("bn_bwd_finalize");
     if (rc || !gamma) return rc;
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",

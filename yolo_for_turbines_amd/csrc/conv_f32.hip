@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 // ------------------------------------------------------------------------------ host side
 
 
-constexpr int kNumTiles = 9;      // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU); 8: 16-bit only (conv3_dma_h16)
+constexpr int kNumTiles = 10;     // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU); 8-10: 16-bit only (conv3_dma_h16)
+constexpr int kMaxTileId = 31;    // ids above kNumTiles select timing probes of the diagnostic library (make probes); the product library runs tile 8 for them
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }
 
@@ -311,7 +312,7 @@ static int validate(const yolo_conv_desc* d) {
     if (d->x_ld < cp + 0 || (d->x_ld & 3) || (d->x_off & 3)) return fail(YOLO_ERR_ARG, "conv: x_ld/x_off must be multiples of 4 and x_ld >= cin_pad");
     if (d->out_mode == YOLO_OUT_HEAD && d->cout % 3 != 0) return fail(YOLO_ERR_ARG, "conv: head cout %% 3 != 0");
     if (d->out_mode < 0 || d->out_mode > 2) return fail(YOLO_ERR_ARG, "conv: out_mode");
-    if (d->tile < 0 || d->tile > kNumTiles) return fail(YOLO_ERR_ARG, "conv: tile id");
+    if (d->tile < 0 || d->tile > kMaxTileId) return fail(YOLO_ERR_ARG, "conv: tile id");
     return YOLO_OK;
 }
 
@@ -341,7 +342,7 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     a.tiles_n = 0;
     const bool smallc = a.Cin == 4;
     const int t = d->tile ? d->tile : pick_tile(d);
-    if (t >= 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tiles 8 and 9 are 16-bit kernels (conv3_dma_h16)");
+    if (t >= 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile ids from 8 up are 16-bit kernels (conv3_dma_h16)");
     if (t >= 5) {
         if (!v2_eligible(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile %d needs stride 1 and cin %% 32 == 0", t);
         const float* wf = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize);

@@ -49,6 +49,7 @@ struct ConvHArgs {
     int Ho, Wo;
     int first_wave, stagger;
     int prio;                            // conv3_dma_h16: prologue / epilogue at s_setprio 2 (A/B switch YOLO_DMA_PRIO=0)
+    unsigned qperm;                      // conv3_dma_h16: nibble q = pixel quad of lane quad q within a 32-pixel m-tile
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
     // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
     // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
@@ -769,13 +770,16 @@ struct DRes {                       // residual rows of the epilogue, requested 
     bool has_res;
 };
 
-template <typename T, int BN, int TAP, bool P16, bool LAST>
+template <typename T, int BN, int TAP, int PROBE, bool LAST>
 __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
                                         const unsigned short*& wp, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
                                         f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh, const DRes& rs,
                                         u32x4 (&rr)[2][BN / 64][2]) {
     typedef typename HTraits<T>::vec vec;
     constexpr int TN = BN / 64;
+    constexpr bool P16 = PROBE & 16;                        // PROBE bits (diagnostic builds only, results are garbage): 1 no s_barrier per
+    constexpr bool NOBAR = PROBE & 1, NOWDMA = PROBE & 2;   // step, 2 no weight DMA, 4 no patch fragment reads, 8 no weight fragment reads,
+    constexpr bool NOAREAD = PROBE & 4, NOBREAD = PROBE & 8;// 16 the 16x16x32 MFMA shape
     static_assert(TN == 2, "the interleave below is written for 2 x 2 tiles per wave");
     constexpr int SLOT_BYTES = (BN / 32) * 2048;
     // The WEIGHT fragment is the MFMA's A operand and the activation fragment its B operand (the two operand layouts are
@@ -796,7 +800,7 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(0, 0, 0);
     constexpr bool last = LAST;                             // the last chunk of a tile is its own instantiation
-    constexpr bool fetch = TAP < 9 - D_P || !last;          // nothing to fetch in the last D_P steps
+    constexpr bool fetch = (TAP < 9 - D_P || !last) && !NOWDMA;   // nothing to fetch in the last D_P steps
     if (LAST && TAP == 7 && rs.has_res) {                   // residual rows, first half (see the note at the wait below)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -813,21 +817,28 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     {   // (2) activation fragments of step t + 1 (landed and made visible by the wait + barrier that closed step t - 1)
         const int px = c.p0[0] + nkh * c.PC + nkw;
         const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);              // granule (s = 0) = fh, swizzled
+        if (NOAREAD) { an[0][0] = af[0][0]; an[0][1] = af[0][1]; } else {
         an[0][0] = *reinterpret_cast<const u32x4*>(pb + a0);
         an[0][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));            // granule 2 + fh
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(0, 1, 0);
     {
         const int px = c.p0[1] + nkh * c.PC + nkw;
         const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);
+        if (NOAREAD) { an[1][0] = af[1][0]; an[1][1] = af[1][1]; } else {
         an[1][0] = *reinterpret_cast<const u32x4*>(pb + a0);
         an[1][1] = *reinterpret_cast<const u32x4*>(pb + (a0 ^ 32));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(1, 1, 0);
+    if (NOBREAD) { bn[0][0] = bf[0][0]; bn[1][0] = bf[1][0]; bn[0][1] = bf[0][1]; bn[1][1] = bf[1][1]; }
+    if (!NOBREAD) {
     bn[0][0] = *reinterpret_cast<const u32x4*>(wb);                            // (3) weight fragments of step t + 1
     bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
+    }
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(0, 0, 1);
     if (fetch) {                                            // ... second KiB four MFMAs later (a request costs ~60 cycles of issue, an
@@ -835,8 +846,10 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
         wp += 1024;
         slot_w = slot_w + 1 == D_SLOTS ? 0 : slot_w + 1;
     }
+    if (!NOBREAD) {
     bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
     bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
+    }
     slot_r = slot_r + 1 == D_SLOTS ? 0 : slot_r + 1;
     __builtin_amdgcn_sched_barrier(0);
     D_MFMA(1, 0, 1);
@@ -880,22 +893,108 @@ __device__ __forceinline__ void d_kstep(const ConvHArgs& p, const DCtx<T, BN / 6
     else if (TAP == 6) { if (last) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
     else if (TAP >= 7) { if (!last) wait_vmcnt<4>(); }
     else wait_vmcnt<4>();
-    __builtin_amdgcn_s_barrier();
+    if (!NOBAR) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int BN, int TAP, bool P16, bool LAST>
+template <typename T, int BN, int TAP, int PROBE, bool LAST>
 __device__ __forceinline__ void d_chunk(const ConvHArgs& p, const DCtx<T, BN / 64>& c, int chunk, char* patch, char* wring,
                                         const unsigned short*& wp, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][BN / 64],
                                         f32x16 (&acc)[2][BN / 64], int wave, int lane, int wn, int fh, const DRes& rs,
                                         u32x4 (&rr)[2][BN / 64][2]) {
     if constexpr (TAP < 9) {
-        d_kstep<T, BN, TAP, P16, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
-        d_chunk<T, BN, TAP + 1, P16, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        d_kstep<T, BN, TAP, PROBE, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        d_chunk<T, BN, TAP + 1, PROBE, LAST>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
     }
 }
 
-template <typename T, int BN, bool P16 = false>
+// ---- epilogue of conv3_dma_h16 (fp32 math, from registers)
+// acc[i][j]: rows = the 32 channels of this wave's n-tile j, columns = the 32 pixels of m-tile i. A lane owns pixel
+// (lane & 31) and channels 8g + 4h + {0..3} (g = 0..3, h = lane >> 5). Scale / shift / activation in that layout; then
+// one v_permlane32_swap per register pair exchanges halves so that lanes 0-31 hold channels 8k .. 8k+7 and lanes 32-63
+// channels 8k+8 .. 8k+15 of their pixel (k = 0, 2): 16 contiguous bytes of output per lane -> ONE 16-byte store (and one
+// 16-byte residual row, requested inside the last chunk) per lane, pixel and 16 channels. No LDS round trip, no barrier
+// (cdna_hip_programming.md T21). Phases: (A) arithmetic of all four tiles, (B) ALL residual adds, (C) NaN guard + one
+// rounding, (D) the stores - nothing that could wait on memory sits between two stores.
+template <typename T, int BN, int ACT, bool RES>
+__device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const u32x4 (&rr)[2][BN / 64][2],
+                                           const float* sstab, const int (&mpix)[2], const size_t (&ooff)[2], int ch0, int wn, int fh) {
+    constexpr int TN = BN / 64;
+    float w[2][TN][2][8];           // w[i][j][kp][0..7] = this lane's 8 consecutive output channels (ch0 + j*64 + kp*16 ...) of pixel mpix[i]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        // folded BatchNorm scale / shift of channels 8g + 4h + {0..3}: broadcast reads of the table the prologue staged
+        f32x4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(sstab + j * 64 + wn * 32 + 8 * g + 4 * fh);
+            sh4[g] = *reinterpret_cast<const f32x4*>(sstab + BN + j * 64 + wn * 32 + 8 * g + 4 * fh);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = act_c<ACT>(acc[i][j][r] * sc4[r >> 2][r & 3] + sh4[r >> 2][r & 3]);
+            // half exchange on the fp32 values (one rounding, after the residual add): group pairs (0,1) and (2,3)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * kp + e]), __float_as_uint(v[8 * kp + 4 + e]), false, false);
+                    w[i][j][kp][e] = __uint_as_float(sw[0]);          // lanes 0-31: own group 2kp | lanes 32-63: lower half's group 2kp+1
+                    w[i][j][kp][4 + e] = __uint_as_float(sw[1]);      // lanes 0-31: upper half's group 2kp | lanes 32-63: own group 2kp+1
+                }
+        }
+    }
+    if (RES) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w[i][j][kp][2 * e] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] & 0xffffu));
+                        w[i][j][kp][2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] >> 16));
+                    }
+    }
+    bool saw_nan = false;
+    u32x4 o[2][TN][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = w[i][j][kp][2 * e], x1 = w[i][j][kp][2 * e + 1];
+                    saw_nan |= __builtin_isunordered(x0, x1);          // one v_cmp_u_f32 per pair
+                    o[i][j][kp][e] = pack2<T>(x0, x1);
+                }
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                if (mpix[i] < 0 || ch0 + j * 64 + kp * 16 >= p.Cout) continue;
+                unsigned short* d = yo + ooff[i] + j * 64 + kp * 16;
+                *reinterpret_cast<u32x4*>(d) = o[i][j][kp];
+                if (p.out_mode != YOLO_OUT_NHWC) {
+                    const size_t W2 = 2 * (size_t)p.Wo;
+                    *reinterpret_cast<u32x4*>(d + p.y_ld) = o[i][j][kp];
+                    *reinterpret_cast<u32x4*>(d + W2 * p.y_ld) = o[i][j][kp];
+                    *reinterpret_cast<u32x4*>(d + (W2 + 1) * p.y_ld) = o[i][j][kp];
+                }
+            }
+    return saw_nan;
+}
+
+
+template <typename T, int BN, int PROBE = 0>
 __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     constexpr int TN = BN / 64;
     constexpr int SLOT_BYTES = (BN / 32) * 2048;
@@ -992,17 +1091,18 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     // while those travel: fragment rows and the tile-row -> output-pixel tables of the epilogue
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int pp = wm * 64 + i * 32 + frow;
+        const int pp = wm * 64 + i * 32 + ((((p.qperm >> ((frow >> 2) * 4)) & 7) << 2) | (frow & 3));
         const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
         const int g = g0 + r;
         const bool ok = (pp < p.TH * p.TW) & (g <= g_last) & (c0 + cc < p.W);
         c.p0[i] = ok ? (vrow(g) - v0) * p.PC + cc : 0;
     }
     if (tid < 128) {
-        const int r = fdiv(tid, p.mg_TW, p.TW), cc = tid - r * p.TW;
+        const int pp = (tid & ~31) | (((p.qperm >> (((tid & 31) >> 2) * 4)) & 7) << 2) | (tid & 3);
+        const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
         const int g = g0 + r;
         int m = -1, mh = 0;
-        if (tid < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
+        if (pp < p.TH * p.TW && g <= g_last && c0 + cc < p.W) {
             m = g * p.W + c0 + cc;
             if (p.out_mode == YOLO_OUT_HEAD) mh = m + 2 * (m / (p.Ho * p.Wo)) * (p.Ho * p.Wo);
         }
@@ -1063,8 +1163,8 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
             }
     }
     for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk)
-        d_chunk<T, BN, 0, P16, false>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
-    d_chunk<T, BN, 0, P16, true>(p, c, p.nchunks - 1, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        d_chunk<T, BN, 0, PROBE, false>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+    d_chunk<T, BN, 0, PROBE, true>(p, c, p.nchunks - 1, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
     if (p.prio) __builtin_amdgcn_s_setprio(2);
 #ifdef H16_STAMPS
     asm volatile("s_nop 0" ::: "memory");
@@ -1078,7 +1178,6 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     // channels 8k+8 .. 8k+15 of their pixel (k = 0, 2): 16 contiguous bytes of output per lane -> ONE 16-byte store (and one
     // 16-byte residual load) per lane, pixel and 16 channels. No LDS round trip, no barrier (cdna_hip_programming.md T21).
     const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
-    bool saw_nan = false;
     const int ch0 = rs.ch0;                                           // + j * 64 + 16 * kp: first of this lane's 8 output channels
     size_t ooff[2];
 #pragma unroll
@@ -1095,67 +1194,13 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
             ooff[i] = ((size_t)(img * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo2) * p.y_ld + p.y_off + ch0;
         }
     }
-    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
-    // phase A (needs no memory): scale / shift / activation and the half exchange of all four tiles. w[i][j][kp][0..7] =
-    // this lane's 8 consecutive output channels (ch0 + j*64 + kp*16 ...) of pixel mpix[i]. The residual rows requested
-    // above arrive meanwhile.
-    float w[2][TN][2][8];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        // folded BatchNorm scale / shift of channels 8g + 4h + {0..3}: broadcast reads of the table the prologue staged
-        f32x4 sc4[4], sh4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            sc4[g] = *reinterpret_cast<const f32x4*>(sstab + j * 64 + wn * 32 + 8 * g + 4 * fh);
-            sh4[g] = *reinterpret_cast<const f32x4*>(sstab + BN + j * 64 + wn * 32 + 8 * g + 4 * fh);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v[16];
-            YOLO_SWITCH_ACT(p.act,
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = act_c<ACT>(acc[i][j][r] * sc4[r >> 2][r & 3] + sh4[r >> 2][r & 3]);)
-            // half exchange on the fp32 values (one rounding, after the residual add): group pairs (0,1) and (2,3)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * kp + e]), __float_as_uint(v[8 * kp + 4 + e]), false, false);
-                    w[i][j][kp][e] = __uint_as_float(sw[0]);          // lanes 0-31: own group 2kp | lanes 32-63: lower half's group 2kp+1
-                    w[i][j][kp][4 + e] = __uint_as_float(sw[1]);      // lanes 0-31: upper half's group 2kp | lanes 32-63: own group 2kp+1
-                }
-        }
-    }
-    // phase B: residual add, NaN guard, one rounding, 16-byte stores
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                float (&x)[8] = w[i][j][kp];
-                if (has_res) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] & 0xffffu));
-                        x[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] >> 16));
-                    }
-                }
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (nan_chk && (x[2 * e] != x[2 * e] || x[2 * e + 1] != x[2 * e + 1])) saw_nan = true;
-                    o[e] = pack2<T>(x[2 * e], x[2 * e + 1]);
-                }
-                if (mpix[i] < 0 || ch0 + j * 64 + kp * 16 >= p.Cout) continue;
-                unsigned short* d = yo + ooff[i] + j * 64 + kp * 16;
-                *reinterpret_cast<u32x4*>(d) = o;
-                if (p.out_mode != YOLO_OUT_NHWC) {
-                    const size_t W2 = 2 * (size_t)p.Wo;
-                    *reinterpret_cast<u32x4*>(d + p.y_ld) = o;
-                    *reinterpret_cast<u32x4*>(d + W2 * p.y_ld) = o;
-                    *reinterpret_cast<u32x4*>(d + (W2 + 1) * p.y_ld) = o;
-                }
-            }
+    // One straight-line instance per (activation, residual): chosen by ONE wave-uniform switch here. With the switch inside the
+    // tile loops hipcc merged the variants through ~190 v_mov and a branch per tile, and with the residual add between the
+    // stores every add waited for the stores before it (s_waitcnt vmcnt(0): one in-order counter, and the rows were requested
+    // in another basic block) — ~500 cycles per store group on the 23 residual layers.
+    bool saw_nan = false;
+    YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
+                                             : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
 #ifdef H16_STAMPS
     {
@@ -1448,15 +1493,27 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    if (a.cls_ph == 9) {                                    // tile 9: MFMA-shape speed probe (garbage results), bf16 only
-        static bool configured9 = false;
-        if (!configured9) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_h16<__bf16, BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            configured9 = true;
+#ifdef H16_PROBES
+    // diagnostic library only (make probes): tile 9 = MFMA-shape probe, tiles 16 + bits = ablations of the K step (d_kstep)
+    {
+        auto go = [&](auto kern, const char* what) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds, s, a);
+            return check_launch(what);
+        };
+        switch (a.cls_ph) {
+            case 9: return go(&conv3_dma_h16<__bf16, BN, 16>, "conv3_dma_h16 (probe 16)");
+            case 17: return go(&conv3_dma_h16<__bf16, BN, 1>, "conv3_dma_h16 (probe 1)");
+            case 18: return go(&conv3_dma_h16<__bf16, BN, 2>, "conv3_dma_h16 (probe 2)");
+            case 19: return go(&conv3_dma_h16<__bf16, BN, 3>, "conv3_dma_h16 (probe 3)");
+            case 20: return go(&conv3_dma_h16<__bf16, BN, 4>, "conv3_dma_h16 (probe 4)");
+            case 24: return go(&conv3_dma_h16<__bf16, BN, 8>, "conv3_dma_h16 (probe 8)");
+            case 28: return go(&conv3_dma_h16<__bf16, BN, 12>, "conv3_dma_h16 (probe 12)");
+            case 31: return go(&conv3_dma_h16<__bf16, BN, 15>, "conv3_dma_h16 (probe 15)");
+            default: break;
         }
-        hipLaunchKernelGGL((conv3_dma_h16<__bf16, BN, true>), dim3(a.nblocks), dim3(256), lds, s, a);
-        return check_launch("conv3_dma_h16 (probe)");
     }
+#endif
     hipLaunchKernelGGL((conv3_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv3_dma_h16");
 }
@@ -1556,7 +1613,8 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048 && d->cout % 8 == 0 && d->out_mode != YOLO_OUT_HEAD &&
                         (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0));
     if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
-    const bool use_dma = dma_ok && (d->tile == 8 || d->tile == 9 || (d->tile == 0 && g_h_dma));
+    const bool use_dma = dma_ok && (d->tile >= 8 || (d->tile == 0 && g_h_dma));
+    a.qperm = d->tile == 10 ? 0x76452310u : 0x76543210u;
     a.cls_ph = d->tile;
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
