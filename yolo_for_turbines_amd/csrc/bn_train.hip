@@ -162,7 +162,8 @@ __device__ __forceinline__ bool reduce_partials(const double* __restrict__ parti
     __syncthreads();
     if (lane != 0 || ch >= c) return false;
     s = 0; q = 0;
-    for (int l = 0; l < FIN_LANES; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }
+#pragma unroll 4
+    for (int l = 0; l < FIN_LANES; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }   // (fully unrolled, hipcc spilled 64 LDS reads to scratch)
     *ch_out = ch; *s_out = s; *q_out = q;
     return true;
 }
