@@ -51,7 +51,7 @@ def host_cores():
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_H16_MFMA_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA peak (not the 2:1-sparsity marketing figure)
 TRAFFIC_F32_C52 = 146.8e6             # PMC: 58.2 MB read (x2-corrected) + 88.6 MB written, conv_patch_f32<3,64> 128->256 @52x52 B=32
-TRAFFIC_H16_C52 = None                # PMC: conv3_dma_h16 128->256 @52x52 B=32 (profiles/r02/pmc_hbm_traffic.txt)
+TRAFFIC_H16_C52 = 71.8e6              # PMC: 27.5 MB read (x2-corrected) + 44.3 MB written, conv3_dma_h16 128->256 @52x52 B=32 (profiles/r02/pmc_hbm_traffic.txt)
 GFLOP_PER_IMAGE_416_NC80 = 65.864     # BASELINE.md §2 (75 convs, 2*Ho*Wo*Cout*Cin*k^2)
 
 
