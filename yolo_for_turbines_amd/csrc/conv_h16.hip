@@ -914,8 +914,8 @@ __device__ __forceinline__ void d_chunk(const ConvHArgs& p, const DCtx<T, BN / 6
 // one v_permlane32_swap per register pair exchanges halves so that lanes 0-31 hold channels 8k .. 8k+7 and lanes 32-63
 // channels 8k+8 .. 8k+15 of their pixel (k = 0, 2): 16 contiguous bytes of output per lane -> ONE 16-byte store (and one
 // 16-byte residual row, requested inside the last chunk) per lane, pixel and 16 channels. No LDS round trip, no barrier
-// (cdna_hip_programming.md T21). Phases: (A) arithmetic of all four tiles, (B) ALL residual adds, (C) NaN guard + one
-// rounding, (D) the stores - nothing that could wait on memory sits between two stores.
+// (cdna_hip_programming.md T21). Phases: (A) arithmetic of all four tiles, (B) ALL residual adds, (C) per 16-byte group: NaN guard,
+// one rounding, store - nothing that could wait on memory sits between two stores.
 template <typename T, int BN, int ACT, bool RES>
 __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const u32x4 (&rr)[2][BN / 64][2],
                                            const float* sstab, const int (&mpix)[2], const size_t (&ooff)[2], int ch0, int wn, int fh) {
@@ -944,8 +944,10 @@ __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&ac
                     w[i][j][kp][e] = __uint_as_float(sw[0]);          // lanes 0-31: own group 2kp | lanes 32-63: lower half's group 2kp+1
                     w[i][j][kp][4 + e] = __uint_as_float(sw[1]);      // lanes 0-31: upper half's group 2kp | lanes 32-63: own group 2kp+1
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);      // phases stay phases: overlapped by the scheduler they were all live at once (250 VGPRs)
     if (RES) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -958,21 +960,9 @@ __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&ac
                         w[i][j][kp][2 * e] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] & 0xffffu));
                         w[i][j][kp][2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] >> 16));
                     }
+        __builtin_amdgcn_sched_barrier(0);
     }
     bool saw_nan = false;
-    u32x4 o[2][TN][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = w[i][j][kp][2 * e], x1 = w[i][j][kp][2 * e + 1];
-                    saw_nan |= __builtin_isunordered(x0, x1);          // one v_cmp_u_f32 per pair
-                    o[i][j][kp][e] = pack2<T>(x0, x1);
-                }
     unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -980,14 +970,21 @@ __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&ac
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = w[i][j][kp][2 * e], x1 = w[i][j][kp][2 * e + 1];
+                    saw_nan |= __builtin_isunordered(x0, x1);          // one v_cmp_u_f32 per pair
+                    o[e] = pack2<T>(x0, x1);
+                }
                 if (mpix[i] < 0 || ch0 + j * 64 + kp * 16 >= p.Cout) continue;
                 unsigned short* d = yo + ooff[i] + j * 64 + kp * 16;
-                *reinterpret_cast<u32x4*>(d) = o[i][j][kp];
+                *reinterpret_cast<u32x4*>(d) = o;
                 if (p.out_mode != YOLO_OUT_NHWC) {
                     const size_t W2 = 2 * (size_t)p.Wo;
-                    *reinterpret_cast<u32x4*>(d + p.y_ld) = o[i][j][kp];
-                    *reinterpret_cast<u32x4*>(d + W2 * p.y_ld) = o[i][j][kp];
-                    *reinterpret_cast<u32x4*>(d + (W2 + 1) * p.y_ld) = o[i][j][kp];
+                    *reinterpret_cast<u32x4*>(d + p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + W2 * p.y_ld) = o;
+                    *reinterpret_cast<u32x4*>(d + (W2 + 1) * p.y_ld) = o;
                 }
             }
     return saw_nan;
@@ -1088,6 +1085,11 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     }
 #pragma unroll
     for (int q = 2; q < D_P; ++q) issue_w(q);
+    if constexpr ((PROBE & 96) != 0) {   // NEGATIVE ablation: 1k (bit 32) / 2k (bit 64) cycles of extra quarter-rate VALU work per wave
+        int xx = tid | 1;                // and tile, while the first operands travel: is a block's VALU time hidden or additive?
+#pragma unroll
+        for (int k = 0; k < ((PROBE & 64) ? 128 : 64); ++k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(xx) : "v"(tid | 3));
+    }
     // while those travel: fragment rows and the tile-row -> output-pixel tables of the epilogue
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1218,6 +1220,242 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
 #endif
 }
 
+#ifdef H16_PROBES
+// ---- conv3_dmap_h16: the same K step and epilogue in a PERSISTENT block. DIAGNOSTIC LIBRARY ONLY (make probes, tile id 11):
+// correct (stress-tested with a grid of 7 blocks) and measured at 0 to -7 % against conv3_dma_h16 - see DESIGN 4.5. --------------
+// Per-block stamps of conv3_dma_h16 (128->256 @52x52): 2.1k cycles between a block's end and its successor's start, 3.8k of
+// prologue (mostly the latency of the first patch + two weight steps), 19.5k of main loop, 4.4k of epilogue. Here a block walks
+// tiles t = blockIdx.x, + gridDim.x, ... and requests the NEXT tile's first operands (weight steps 0-1, scale / shift, patch of
+// chunk 0) right after its main loop, when only the accumulators are live, so that they travel during the epilogue:
+//   * every wave has passed the last K step's barrier, so nobody reads the weight ring or the patch any more; scale / shift
+//     are double-buffered by tile parity (the epilogue still reads this tile's);
+//   * weight steps 2-3 follow the epilogue's stores, so that the loop-top wait stays the counted vmcnt(4): everything older
+//     than those four requests - the prefetches AND the stores - has completed (the store drain overlaps the lane-row math);
+//   * the lane-row geometry (p0, output pixels) and the patch source pointers of the next tile are recomputed after the
+//     epilogue instead of being carried through it (the epilogue peaks at ~250 VGPRs).
+template <typename T, int BN, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv3_dmap_h16(const ConvHArgs p) {
+    constexpr int TN = BN / 64;
+    constexpr int SLOT_BYTES = (BN / 32) * 2048;
+    static_assert(BN / 32 == 4, "one weight n-tile per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* patch = smem_raw;                                             // [2][256 px][64 B]
+    char* wring = smem_raw + 2 * D_PATCH_BYTES;                         // [D_SLOTS][BN/32][2 KiB]
+    float* sstab2 = reinterpret_cast<float*>(wring + D_SLOTS * SLOT_BYTES);   // [2 (tile parity)][BN scale | BN shift]
+
+    // Per-lane index values are RE-DERIVED from an opaque copy of the thread id at every phase of the tile loop (refresh()):
+    // left loop-invariant, hipcc hoists every address computed from them out of the loop and keeps them all alive across it
+    // (256 VGPRs + 22 AGPRs and 5.7 KB of scratch per lane when forced to two blocks per CU).
+    int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int fh = lane >> 5, frow = lane & 31;
+
+    if (p.stagger > 0 && (int)blockIdx.x < p.first_wave) {             // see conv_f32_v2.hip
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int slot = (hw >> 16) & 15;
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
+
+    const int Hp = p.Hin + 2;
+    int gs = (tid & 3) ^ ((tid >> 4) & 3);                             // source granule of LDS granule (pixel (tid>>2) + 64 i, slot tid & 3)
+    const unsigned short* zp = reinterpret_cast<const unsigned short*>(g_zero_page) + gs * 8;
+    auto refresh = [&]() {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        tid = (int)threadIdx.x + z;
+        lane = tid & 63;
+        fh = lane >> 5;
+        frow = lane & 31;
+        gs = (tid & 3) ^ ((tid >> 4) & 3);
+        zp = reinterpret_cast<const unsigned short*>(g_zero_page) + gs * 8;
+    };
+    auto vrow = [&](int g) {
+        const int n = fdiv(g, p.mg_H, p.H);
+        return n * Hp + (g - n * p.H);
+    };
+    struct Geom { int n_tile, g0, c0, g_last, v0, PR; };
+    auto geom_of = [&](int t) {
+        const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = t % 8;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + t / 8;
+        const int sp = fdiv(bid, p.mg_tn, p.tiles_n);
+        Geom g;
+        g.n_tile = bid - sp * p.tiles_n;
+        const int r_tile = fdiv(sp, p.mg_tw, p.tiles_w);
+        const int w_tile = sp - r_tile * p.tiles_w;
+        g.g0 = r_tile * p.TH;
+        g.c0 = w_tile * p.TW;
+        g.g_last = (g.g0 + p.TH < p.rows_total ? g.g0 + p.TH : p.rows_total) - 1;
+        g.v0 = vrow(g.g0);
+        g.PR = vrow(g.g_last) + 3 - g.v0;
+        return g;
+    };
+    auto wsrc_of = [&](const Geom& g) { return p.wf + (size_t)(g.n_tile * (BN / 32) + wave) * p.KT * 1024 + lane * 8; };
+    auto issue_w = [&](const unsigned short* wsrc, int q) {
+        const int kq = q < p.KT ? q : p.KT - 1;
+        const unsigned short* src = wsrc + (size_t)kq * 1024;
+        char* dst = wring + q * SLOT_BYTES + wave * 2048;
+        glds16(src, dst);
+        glds16(src + 512, dst + 1024);
+    };
+    auto issue_ss = [&](const Geom& g, int par) {                      // 4 bytes per lane; waves 0-1 scale, 2-3 shift
+        const int n = g.n_tile * BN + (wave & 1) * 64 + lane;
+        const int ncl = n < p.Cout ? n : p.Cout - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)((wave < 2 ? p.scale : p.shift) + ncl), (lptr_t)(sstab2 + par * 2 * BN + wave * 64), 4, 0, 0);
+    };
+    auto patch_src = [&](const Geom& g, const unsigned short* (&psrc)[D_NI]) {
+#pragma unroll
+        for (int i = 0; i < D_NI; ++i) {
+            const int idx = (tid >> 2) + 64 * i;
+            const int pr = fdiv(idx, p.mg_PC, p.PC), pc = idx - pr * p.PC;
+            const int vv = g.v0 + pr;
+            const int n = fdiv(vv, p.mg_Hp, Hp), yy = vv - n * Hp;
+            const int hi = yy - 1, wi = g.c0 + pc - 1;
+            const bool ok = (pr < g.PR) & ((unsigned)hi < (unsigned)p.Hin) & ((unsigned)wi < (unsigned)p.Win);
+            const int pix = (n * p.Hin + hi) * p.Win + wi;
+            psrc[i] = ok ? p.x + (size_t)pix * p.x_ld + p.x_off + gs * 8 : zp;
+        }
+    };
+    auto issue_patch = [&](const unsigned short* const (&psrc)[D_NI]) {
+        char* dst = patch + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < D_NI; ++i) glds16(psrc[i], dst + i * 4096);
+    };
+    auto lane_rows = [&](const Geom& g, int (&p0)[2], int (&mpix)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pp = wm * 64 + i * 32 + ((((p.qperm >> ((frow >> 2) * 4)) & 7) << 2) | (frow & 3));
+            const int r = fdiv(pp, p.mg_TW, p.TW), cc = pp - r * p.TW;
+            const int gg = g.g0 + r;
+            const bool ok = (pp < p.TH * p.TW) & (gg <= g.g_last) & (g.c0 + cc < p.W);
+            p0[i] = ok ? (vrow(gg) - g.v0) * p.PC + cc : 0;
+            mpix[i] = ok ? gg * p.W + g.c0 + cc : -1;
+        }
+    };
+
+    DCtx<T, TN> c;
+    c.KT = p.KT;
+    c.PC = p.PC;
+    int mpix[2];
+    int t = blockIdx.x;
+    Geom g = geom_of(t);
+    c.wsrc = wsrc_of(g);
+    issue_w(c.wsrc, 0);
+    issue_w(c.wsrc, 1);
+    issue_ss(g, 0);
+    patch_src(g, c.psrc);
+    issue_patch(c.psrc);
+#pragma unroll
+    for (int q = 2; q < D_P; ++q) issue_w(c.wsrc, q);
+    lane_rows(g, c.p0, mpix);
+    constexpr bool has_res = RES;
+    const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
+    bool saw_nan = false;
+    int par = 0;
+    for (;;) {
+        // weights of steps 0 and 1, scale / shift and the patch of chunk 0 have landed (and, from the second tile on, the previous
+        // tile's stores have completed); steps 2 .. D_P-1 stay in flight - the same count the loop keeps
+        wait_vmcnt<2 * (D_P - 2)>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        refresh();
+        u32x4 af[2][2], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = c.p0[i];
+            const int a0 = (px << 6) | ((((px >> 2) ^ fh) & 3) << 4);
+            af[i][0] = *reinterpret_cast<const u32x4*>(patch + a0);
+            af[i][1] = *reinterpret_cast<const u32x4*>(patch + (a0 ^ 32));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf[0][j] = *reinterpret_cast<const u32x4*>(wring + wn * 2048 + lane * 16 + j * 4096);
+            bf[1][j] = *reinterpret_cast<const u32x4*>(wring + wn * 2048 + lane * 16 + j * 4096 + 1024);
+        }
+        f32x16 acc[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        int slot_w = D_P % D_SLOTS, slot_r = 1;
+        const unsigned short* wp = c.wsrc + (size_t)D_P * 1024;
+        __builtin_amdgcn_s_setprio(0);
+        DRes rs;
+        rs.ch0 = g.n_tile * BN + wn * 32 + 8 * fh;
+        rs.has_res = has_res;
+        u32x4 rr[2][TN][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rs.rptr[i] = p.res + (size_t)(mpix[i] < 0 ? 0 : mpix[i]) * p.r_ld + p.r_off;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    rr[i][j][kp] = z;
+                }
+        }
+        for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk)
+            d_chunk<T, BN, 0, 0, false>(p, c, chunk, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        d_chunk<T, BN, 0, 0, true>(p, c, p.nchunks - 1, patch, wring, wp, slot_w, slot_r, af, bf, acc, wave, lane, wn, fh, rs, rr);
+        if (p.prio) __builtin_amdgcn_s_setprio(2);
+
+        // ---- the next tile's first operands leave now (see the header)
+        const int tn = t + (int)gridDim.x;
+        const bool has_next = tn < p.nblocks;
+        Geom gn = g;
+        refresh();
+        if (has_next) {
+            gn = geom_of(tn);
+            const unsigned short* wn_src = wsrc_of(gn);
+            issue_w(wn_src, 0);
+            issue_w(wn_src, 1);
+            issue_ss(gn, par ^ 1);
+            const unsigned short* ps[D_NI];
+            patch_src(gn, ps);
+            issue_patch(ps);
+        }
+        // ---- epilogue of this tile
+        refresh();
+        const int ch0 = g.n_tile * BN + wn * 32 + 8 * fh;
+        size_t ooff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mpix[i] < 0 ? 0 : mpix[i];
+            if (p.out_mode == YOLO_OUT_NHWC) {
+                ooff[i] = (size_t)m * p.y_ld + p.y_off + ch0;
+            } else {                                                  // 2x nearest upsample into the concat buffer
+                const int HoWo = p.Ho * p.Wo;
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo2 = rem - ho * p.Wo;
+                ooff[i] = ((size_t)(img * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo2) * p.y_ld + p.y_off + ch0;
+            }
+        }
+        const float* sstab = sstab2 + par * 2 * BN;
+        saw_nan |= d_epilogue<T, BN, ACT, RES>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh);
+        if (!has_next) break;
+        // ---- the rest of the next tile's prologue: weight steps 2-3 behind the stores, then the per-lane geometry
+        refresh();
+        t = tn;
+        g = gn;
+        par ^= 1;
+        c.wsrc = wsrc_of(g);
+#pragma unroll
+        for (int q = 2; q < D_P; ++q) issue_w(c.wsrc, q);
+        patch_src(g, c.psrc);
+        lane_rows(g, c.p0, mpix);
+    }
+    if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+}
+
+#endif  // H16_PROBES
+
 // fragment-order 16-bit weights: [n_tile32][kt][s(2)][lane(64)][e(8)], n = nt*32 + (lane&31),
 // ci = chunk*32 + s*16 + 8*(lane>>5) + e, (chunk, tap) = divmod(kt, ks*ks)
 template <typename T>
@@ -1295,7 +1533,14 @@ __global__ void pack_batch_h16(const PackBatchH b) {
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
 static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));
 static const bool g_h_prio = !(getenv("YOLO_DMA_PRIO") && getenv("YOLO_DMA_PRIO")[0] == '0');
-static const bool g_h_dma_solo = getenv("YOLO_DMA_SOLO") != nullptr;          // A/B switch: 3x3 stride-1 layers on conv_patch_h16 instead of conv3_dma_h16
+static const bool g_h_dma_solo = getenv("YOLO_DMA_SOLO") != nullptr;          // experiment: one conv3_dma_h16 block per CU (100 KB of LDS)
+#ifdef H16_PROBES
+// diagnostic library: conv3_dmap_h16 (persistent blocks) for tile 0; value = grid cap (a small one exercises the tile loop)
+static const int g_h_dma_persist = getenv("YOLO_DMA_PERSIST") ? atoi(getenv("YOLO_DMA_PERSIST")) : 0;
+static const int g_h_num_cus = 256;                                           // MI355X: 8 XCDs x 32 CUs; two of these blocks per CU
+#else
+static const int g_h_dma_persist = 0;
+#endif
 
 size_t h16_frag_elems(int cout, int cin, int ks) {
     const int cinp = round_up(cin, 32);
@@ -1510,8 +1755,32 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
             case 24: return go(&conv3_dma_h16<__bf16, BN, 8>, "conv3_dma_h16 (probe 8)");
             case 28: return go(&conv3_dma_h16<__bf16, BN, 12>, "conv3_dma_h16 (probe 12)");
             case 31: return go(&conv3_dma_h16<__bf16, BN, 15>, "conv3_dma_h16 (probe 15)");
+            case 21: return go(&conv3_dma_h16<__bf16, BN, 32>, "conv3_dma_h16 (probe 32)");
+            case 22: return go(&conv3_dma_h16<__bf16, BN, 64>, "conv3_dma_h16 (probe 64)");
             default: break;
         }
+    }
+#endif
+#ifdef H16_PROBES
+    if (a.cls_ph == 11) {                                   // persistent blocks with next-tile prefetch (A/B)
+        const size_t lds_p = (size_t)2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048 + 2 * 2 * BN * sizeof(float);
+        const int cap = g_h_dma_persist > 0 ? g_h_dma_persist : 2 * g_h_num_cus;
+        const int grid = a.nblocks < cap ? a.nblocks : cap;
+        auto go = [&](auto kern) {
+            static bool configured_p = false;               // one flag per instantiation of this generic lambda
+            if (!configured_p) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(YOLO_ERR_LAUNCH, "conv3_dmap_h16: cannot reserve %zu bytes of LDS", lds_p);
+                }
+                configured_p = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_p, s, a);
+            return check_launch("conv3_dmap_h16");
+        };
+        const bool res = a.flags & YOLO_FLAG_RESIDUAL;
+        YOLO_SWITCH_ACT(a.act, return res ? go(&conv3_dmap_h16<T, BN, ACT, true>) : go(&conv3_dmap_h16<T, BN, ACT, false>));
+        return fail(YOLO_ERR_ARG, "conv3_dmap_h16: activation");
     }
 #endif
     hipLaunchKernelGGL((conv3_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
@@ -1615,7 +1884,7 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
     const bool use_dma = dma_ok && (d->tile >= 8 || (d->tile == 0 && g_h_dma));
     a.qperm = d->tile == 10 ? 0x76452310u : 0x76543210u;
-    a.cls_ph = d->tile;
+    a.cls_ph = (d->tile == 0 && g_h_dma_persist) ? 11 : d->tile;
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
     } else {
