@@ -1220,6 +1220,235 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
 #endif
 }
 
+// =====================================================================================================
+// conv1_dma_h16 — 1x1 layers with >= 128 output channels on the machinery of conv3_dma_h16.
+//
+// Per-layer times of the 16-bit forward: every 1x1 launch of conv_patch_h16 took 19-21 us whatever its size (52x52 256->128:
+// 66 MB of traffic and 5.7 GFLOP; 13x13 1024->512: 17 MB) - 8-32 K steps per block, each staged through registers, behind a
+// prologue and an LDS epilogue longer than the matrix work. Here a block owns 128 consecutive output pixels x 128 output
+// channels; both operands stream through 5-slot LDS rings by LDS-DMA (activations: [128 px][64 B] per 32-channel step, the
+// 16-byte granules XOR-swizzled by (pixel >> 2) & 3 on the source side; weights: the packed fragment stream), 4 K steps
+// ahead, one counted s_waitcnt vmcnt + one s_barrier per step. 5 x 16 KiB = 80 KiB of LDS exactly (two blocks per CU), so the
+// folded scale / shift table is parked in the ring slot that step KT would have used, requested when the last group begins.
+// Epilogue: d_epilogue (register layout, permlane32 swap, 16-byte stores). Needs Cin >= 128 (KT >= 4), Cout % 8 == 0,
+// no head layout.
+// =====================================================================================================
+constexpr int E_SLOTS = 5;
+constexpr int E_P = 4;                           // K steps in flight
+constexpr int E_A_BYTES = 128 * 64;              // activation slab of one step
+constexpr int E_W_BYTES = 4 * 2048;              // weight slab of one step (BN = 128)
+constexpr int E_SLOT_BYTES = E_A_BYTES + E_W_BYTES;
+
+// LU = -1: a step of the steady loop (requests step t + E_P); LU = 0..3: the last four steps (nothing left to request)
+template <typename T, int LU>
+__device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const unsigned short* const (&asrc)[2], const unsigned short* wsrc,
+                                       int t, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][2], f32x16 (&acc)[2][2],
+                                       int wave, int lane, int wn, const int (&aoff)[2][2], const DRes& rs, u32x4 (&rr)[2][2][2],
+                                       const float* ss_src, int ss_slot) {
+    typedef typename HTraits<T>::vec vec;
+#define E_MFMA(i, j, s) acc[i][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, bf[s][j]), __builtin_bit_cast(vec, af[i][s]), acc[i][j])
+    constexpr bool fetch = LU < 0;
+    u32x4 an[2][2], bn[2][2];
+    const char* ab = ring + slot_r * E_SLOT_BYTES;
+    const char* wb = ab + E_A_BYTES + wn * 2048 + lane * 16;
+    char* dst = ring + slot_w * E_SLOT_BYTES + wave * 2048;
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(0, 0, 0);
+    if (LU == 0)                                              // scale / shift -> the slot step KT would have used (4 bytes per lane)
+        __builtin_amdgcn_global_load_lds((gptr_t)ss_src, (lptr_t)(ring + ss_slot * E_SLOT_BYTES + wave * 256), 4, 0, 0);
+    if (fetch) glds16(wsrc + (size_t)(t + E_P) * 1024, dst + E_A_BYTES);
+    if (LU == 1 && rs.has_res) {                              // residual rows: nothing but scale / shift is requested after them
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int ch = rs.ch0 + j * 64 + kp * 16;
+                rr[0][j][kp] = *reinterpret_cast<const u32x4*>(rs.rptr[0] + (ch < p.Cout ? ch : 0));
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(1, 0, 0);
+    an[0][0] = *reinterpret_cast<const u32x4*>(ab + aoff[0][0]);
+    an[0][1] = *reinterpret_cast<const u32x4*>(ab + aoff[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(0, 1, 0);
+    if (fetch) glds16(wsrc + (size_t)(t + E_P) * 1024 + 512, dst + E_A_BYTES + 1024);
+    an[1][0] = *reinterpret_cast<const u32x4*>(ab + aoff[1][0]);
+    an[1][1] = *reinterpret_cast<const u32x4*>(ab + aoff[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(1, 1, 0);
+    bn[0][0] = *reinterpret_cast<const u32x4*>(wb);
+    bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(0, 0, 1);
+    if (fetch) glds16(asrc[0] + (size_t)(t + E_P) * 32, dst);
+    bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
+    bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(1, 0, 1);
+    if (LU == 1 && rs.has_res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int ch = rs.ch0 + j * 64 + kp * 16;
+                rr[1][j][kp] = *reinterpret_cast<const u32x4*>(rs.rptr[1] + (ch < p.Cout ? ch : 0));
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(0, 1, 1);
+    if (fetch) glds16(asrc[1] + (size_t)(t + E_P) * 32, dst + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    E_MFMA(1, 1, 1);
+#undef E_MFMA
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { af[i][q] = an[i][q]; bf[q][i] = bn[q][i]; }
+    slot_r = slot_r + 1 == E_SLOTS ? 0 : slot_r + 1;
+    slot_w = slot_w + 1 == E_SLOTS ? 0 : slot_w + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    // own requests of step t + 2 have landed. Steady loop: steps t + 3 and t + 4 (8 requests) are younger. Last group: step
+    // KT - 4 leaves step KT - 1 and the scale / shift request (5), step KT - 3 everything but the residual rows; the last two
+    // steps read what is already there and need neither a wait nor a rendezvous
+    if (LU < 0) wait_vmcnt<8>();
+    else if (LU == 0) wait_vmcnt<5>();
+    else if (LU == 1) { if (rs.has_res) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+    if (LU < 2) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
+    static_assert(BN == 128, "4 waves x (2 x 2) tiles of 32 x 32");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* ring = smem_raw;                                              // [E_SLOTS][ 128 px x 64 B | 4 x 2 KiB ]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fh = lane >> 5, frow = lane & 31;
+    int bid = blockIdx.x;
+    {
+        const int nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int sp = fdiv(bid, p.mg_tn, p.tiles_n);                      // pixel tile; the n tiles of one pixel tile are neighbours
+    const int n_tile = bid - sp * p.tiles_n;
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
+    const int M = p.W;                                                  // 1x1: the tiling view is one row of M pixels
+    const unsigned short* wsrc = p.wf + (size_t)(n_tile * (BN / 32) + wave) * p.KT * 1024 + lane * 8;
+    // this lane's two activation rows (DMA rounds 2 wave, 2 wave + 1 of 16 pixels x 4 granules), clamped to the last pixel
+    const unsigned short* asrc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int px = 16 * (2 * wave + r) + (lane >> 2);
+        int m = sp * 128 + px;
+        m = m < M ? m : M - 1;
+        const int gs = (lane & 3) ^ ((px >> 2) & 3);
+        asrc[r] = p.x + (size_t)m * p.x_ld + p.x_off + gs * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < E_P; ++q) {                                    // steps 0 .. 3, four requests each
+        char* dst = ring + q * E_SLOT_BYTES + wave * 2048;
+        glds16(wsrc + (size_t)q * 1024, dst + E_A_BYTES);
+        glds16(wsrc + (size_t)q * 1024 + 512, dst + E_A_BYTES + 1024);
+        glds16(asrc[0] + (size_t)q * 32, dst);
+        glds16(asrc[1] + (size_t)q * 32, dst + 1024);
+    }
+    // fragment rows: byte offsets of this lane's two pixels x two k16 halves inside an activation slab, output pixels
+    int aoff[2][2], mpix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = wm * 64 + i * 32 + frow;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) aoff[i][q] = (px << 6) | ((((2 * q + fh) ^ (px >> 2)) & 3) << 4);
+        const int m = sp * 128 + px;
+        mpix[i] = m < M ? m : -1;
+    }
+    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
+    DRes rs;
+    rs.ch0 = n_tile * BN + wn * 32 + 8 * fh;
+    rs.has_res = has_res;
+    u32x4 rr[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rs.rptr[i] = p.res + (size_t)(mpix[i] < 0 ? 0 : mpix[i]) * p.r_ld + p.r_off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rr[i][j][kp] = z;
+            }
+    }
+    const float* ss_src;                                               // waves 0-1: scale, 2-3: shift of channel (wave & 1) * 64 + lane
+    {
+        const int n = n_tile * BN + (wave & 1) * 64 + lane;
+        ss_src = (wave < 2 ? p.scale : p.shift) + (n < p.Cout ? n : p.Cout - 1);
+    }
+    const int ss_slot = p.KT % E_SLOTS;
+    // step 0 landed; steps 1 .. 3 (12 requests) stay in flight
+    wait_vmcnt<12>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 af[2][2], bf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        af[i][0] = *reinterpret_cast<const u32x4*>(ring + aoff[i][0]);
+        af[i][1] = *reinterpret_cast<const u32x4*>(ring + aoff[i][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bf[0][j] = *reinterpret_cast<const u32x4*>(ring + E_A_BYTES + wn * 2048 + lane * 16 + j * 4096);
+        bf[1][j] = *reinterpret_cast<const u32x4*>(ring + E_A_BYTES + wn * 2048 + lane * 16 + j * 4096 + 1024);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // the loop's invariant at the top of step t: step t + 1 has landed and is visible (step t reads its fragments)
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    int slot_w = E_P % E_SLOTS, slot_r = 1;
+    int t = 0;
+    for (; t + 4 < p.KT; ++t)
+        e_step<T, -1>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+    e_step<T, 0>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+    e_step<T, 1>(p, ring, asrc, wsrc, t + 1, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+    e_step<T, 2>(p, ring, asrc, wsrc, t + 2, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+    e_step<T, 3>(p, ring, asrc, wsrc, t + 3, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
+
+    const float* sstab = reinterpret_cast<const float*>(ring + ss_slot * E_SLOT_BYTES);   // [BN] scale, [BN] shift
+    const bool nan_chk = p.flags & YOLO_FLAG_NANCHECK;
+    const int ch0 = rs.ch0;
+    size_t ooff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mpix[i] < 0 ? 0 : mpix[i];
+        if (p.out_mode == YOLO_OUT_NHWC) {
+            ooff[i] = (size_t)m * p.y_ld + p.y_off + ch0;
+        } else {                                                      // 2x nearest upsample into the concat buffer
+            const int HoWo = p.Ho * p.Wo;
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo2 = rem - ho * p.Wo;
+            ooff[i] = ((size_t)(img * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo2) * p.y_ld + p.y_off + ch0;
+        }
+    }
+    bool saw_nan = false;
+    YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
+                                             : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
+    if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
+}
+
 #ifdef H16_PROBES
 // ---- conv3_dmap_h16: the same K step and epilogue in a PERSISTENT block. DIAGNOSTIC LIBRARY ONLY (make probes, tile id 11):
 // correct (stress-tested with a grid of 7 blocks) and measured at 0 to -7 % against conv3_dma_h16 - see DESIGN 4.5. --------------
@@ -1787,6 +2016,27 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
     return check_launch("conv3_dma_h16");
 }
 
+template <typename T>
+static int launch_dma1(ConvHArgs& a, hipStream_t s) {
+    constexpr int BN = 128;
+    a.tiles_n = ceil_div(a.Cout, BN);
+    a.nblocks = a.tiles_n * ceil_div(a.W, 128);
+    fill_magics(a);
+    a.prio = g_h_prio ? 1 : 0;
+    const size_t lds = (size_t)E_SLOTS * E_SLOT_BYTES;      // 80 KiB: two blocks per CU
+    static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_dma_h16<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YOLO_ERR_LAUNCH, "conv1_dma_h16: cannot reserve %zu bytes of LDS", lds);
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv1_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
+    return check_launch("conv1_dma_h16");
+}
+
 template <typename T, int BN, int MASK>
 static int launch_cls(ConvHArgs& a, hipStream_t s) {
     a.tiles_n = ceil_div(a.Cout, BN);
@@ -1881,10 +2131,24 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     // tile ids (16-bit): 5 / 6 = conv_patch_h16 with 64 / 128 output channels per block, 8 = conv3_dma_h16 (3x3 stride 1)
     const bool dma_ok = d->ksize == 3 && d->stride == 1 && d->cout > 64 && d->cin <= 2048 && d->cout % 8 == 0 && d->out_mode != YOLO_OUT_HEAD &&
                         (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0));
-    if (d->tile == 8 && !dma_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels");
+    // 1x1 with >= 128 output channels and >= 4 K steps: conv1_dma_h16 (tile 8 / default); tiles 5, 6 keep conv_patch_h16
+    const bool dma1_ok = d->ksize == 1 && d->stride == 1 && d->cout >= 128 && d->cin >= 128 && d->cout % 8 == 0 && d->out_mode != YOLO_OUT_HEAD &&
+                         (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0));
+    if (d->tile == 8 && !dma_ok && !dma1_ok)
+        return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels, or 1x1 with >= 128 input and output channels");
     const bool use_dma = dma_ok && (d->tile >= 8 || (d->tile == 0 && g_h_dma));
     a.qperm = d->tile == 10 ? 0x76452310u : 0x76543210u;
     a.cls_ph = (d->tile == 0 && g_h_dma_persist) ? 11 : d->tile;
+    if (dma1_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma))) {
+        a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
+        a.nchunks = d->cin / 32;
+        a.KT = a.nchunks;
+        a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
+        a.nc5 = 1;
+        a.tiles_w = 1; a.first_wave = 0; a.stagger = 0; a.bufmask = 1; a.patch_cap = 128; a.mtab_off = 0;
+        if (d->dtype == YOLO_BF16) return launch_dma1<__bf16>(a, s);
+        return launch_dma1<_Float16>(a, s);
+    }
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
     } else {
