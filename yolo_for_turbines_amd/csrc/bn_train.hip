@@ -194,24 +194,31 @@ __global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, 
     }
 }
 
-// y = act((z - mean)*scale + shift) [+ residual], one 16-byte vector per thread and iteration, same output
-// modes as the conv epilogue
+// y = act((z - mean)*scale + shift) [+ residual], same output modes as the conv epilogue. Thread layout of the reductions
+// (a thread owns one 16-byte channel vector and walks pixels): the per-channel parameters are loaded ONCE per thread, no
+// index division per element, AP_MLP pixels in flight. (The first version was a flat grid-stride loop over (pixel, vector)
+// pairs: 3 parameter vectors + a 64-bit division per 16-byte load, 4.3 TB/s.)
+constexpr int AP_MLP = 4;
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const typename Elt<T>::S* __restrict__ res, int r_ld, int r_off,
-                                                         typename Elt<T>::S* __restrict__ y, int y_ld, int y_off, long long m, int c,
-                                                         int Ho, int Wo, int out_mode, int* nan_flag) {
+                                                         typename Elt<T>::S* __restrict__ y, int y_ld, int y_off, int m, int c,
+                                                         int Ho, int Wo, int out_mode, int pix_per_block, int* nan_flag) {
     constexpr int VN = Vec16<T>::VN;
     const int cv = c / VN;
-    const long long total = m * cv;
+    const RedGeom g = red_geom(cv);
+    const int t = threadIdx.x;
+    const int v = t % g.vc, lane = t / g.vc;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = p0 + pix_per_block < m ? p0 + pix_per_block : m;
     bool bad = false;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / cv;
-        const int ch = (int)(i - p * cv) * VN;
-        float x[VN], v[VN], mu[VN], sc[VN], sh[VN];
-        Vec16<T>::ld(z + (size_t)p * z_ld + z_off + ch, x);
+    for (int pass = 0; pass < g.passes; ++pass) {
+        const int vch = pass * g.vc + v;
+        if (vch >= cv || lane >= g.lanes) continue;
+        const int ch = vch * VN;
+        float mu[VN], sc[VN], sh[VN];
         ldp<VN>(scale + ch, sc);
         ldp<VN>(shift + ch, sh);
         if (mean) ldp<VN>(mean + ch, mu);
@@ -219,29 +226,56 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const typename Elt<T>::
 #pragma unroll
             for (int e = 0; e < VN; ++e) mu[e] = 0.f;
         }
+        const typename Elt<T>::S* zp = z + z_off + ch;
+        const typename Elt<T>::S* rp = res ? res + r_off + ch : nullptr;
+        auto emit = [&](int p, const float (&x)[VN], const float (&r)[VN]) {
+            float o[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) v[e] = act_c<ACT>((x[e] - mu[e]) * sc[e] + sh[e]);
-        if (res) {
-            float r[VN];
-            Vec16<T>::ld(res + (size_t)p * r_ld + r_off + ch, r);
+            for (int e = 0; e < VN; ++e) {
+                o[e] = act_c<ACT>((x[e] - mu[e]) * sc[e] + sh[e]) + r[e];
+                bad |= (o[e] != o[e]);
+            }
+            if (out_mode == YOLO_OUT_UPSAMPLE2X) {
+                const int hw = Ho * Wo;
+                const int img = p / hw;
+                const int rem = p - img * hw;
+                const int ho = rem / Wo, wo = rem - ho * Wo;
+                const int W2 = 2 * Wo;
+                typename Elt<T>::S* d = y + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * y_ld + y_off + ch;
+                Vec16<T>::st(d, o);
+                Vec16<T>::st(d + y_ld, o);
+                Vec16<T>::st(d + (size_t)W2 * y_ld, o);
+                Vec16<T>::st(d + (size_t)(W2 + 1) * y_ld, o);
+            } else {
+                Vec16<T>::st(y + (size_t)p * y_ld + y_off + ch, o);
+            }
+        };
+        int p = p0 + lane;
+        for (; p + (AP_MLP - 1) * g.lanes < p1; p += AP_MLP * g.lanes) {
+            float x[AP_MLP][VN], r[AP_MLP][VN];
 #pragma unroll
-            for (int e = 0; e < VN; ++e) v[e] += r[e];
+            for (int u = 0; u < AP_MLP; ++u) Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * z_ld, x[u]);
+            if (rp) {
+#pragma unroll
+                for (int u = 0; u < AP_MLP; ++u) Vec16<T>::ld(rp + (size_t)(p + u * g.lanes) * r_ld, r[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < AP_MLP; ++u)
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) r[u][e] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < AP_MLP; ++u) emit(p + u * g.lanes, x[u], r[u]);
         }
+        for (; p < p1; p += g.lanes) {
+            float x[VN], r[VN];
+            Vec16<T>::ld(zp + (size_t)p * z_ld, x);
+            if (rp) Vec16<T>::ld(rp + (size_t)p * r_ld, r);
+            else {
 #pragma unroll
-        for (int e = 0; e < VN; ++e) bad |= (v[e] != v[e]);
-        if (out_mode == YOLO_OUT_UPSAMPLE2X) {
-            const long long hw = (long long)Ho * Wo;
-            const long long img = p / hw;
-            const int rem = (int)(p - img * hw);
-            const int ho = rem / Wo, wo = rem - ho * Wo;
-            const int W2 = 2 * Wo;
-            typename Elt<T>::S* d = y + ((size_t)(img * 2 * Ho + 2 * ho) * W2 + 2 * wo) * y_ld + y_off + ch;
-            Vec16<T>::st(d, v);
-            Vec16<T>::st(d + y_ld, v);
-            Vec16<T>::st(d + (size_t)W2 * y_ld, v);
-            Vec16<T>::st(d + (size_t)(W2 + 1) * y_ld, v);
-        } else {
-            Vec16<T>::st(y + (size_t)p * y_ld + y_off + ch, v);
+                for (int e = 0; e < VN; ++e) r[e] = 0.f;
+            }
+            emit(p, x, r);
         }
     }
     if (bad && nan_flag) atomicOr(nan_flag, 2);
@@ -352,16 +386,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ coef, typename Elt<T>::S* __restrict__ dz, int dz_ld,
-                                                    int dz_off, long long m, int c) {
+                                                    int dz_off, int m, int c, int pix_per_block) {
     constexpr int VN = Vec16<T>::VN;
     const int cv = c / VN;
-    const long long total = m * cv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / cv;
-        const int ch = (int)(i - p * cv) * VN;
-        float d[VN], x[VN], o[VN], mu[VN], is[VN], sc[VN], sh[VN], k0[VN], k1[VN], k2[VN];
-        Vec16<T>::ld(dy + (size_t)p * dy_ld + dy_off + ch, d);
-        Vec16<T>::ld(z + (size_t)p * z_ld + z_off + ch, x);
+    const RedGeom g = red_geom(cv);
+    const int t = threadIdx.x;
+    const int v = t % g.vc, lane = t / g.vc;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = p0 + pix_per_block < m ? p0 + pix_per_block : m;
+    for (int pass = 0; pass < g.passes; ++pass) {
+        const int vch = pass * g.vc + v;
+        if (vch >= cv || lane >= g.lanes) continue;
+        const int ch = vch * VN;
+        float mu[VN], is[VN], sc[VN], sh[VN], k0[VN], k1[VN], k2[VN];      // once per thread (see bn_act_fwd_kernel)
         ldp<VN>(mean + ch, mu);
         ldp<VN>(invstd + ch, is);
         ldp<VN>(scale + ch, sc);
@@ -369,13 +406,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __
         ldp<VN>(coef + ch, k0);
         ldp<VN>(coef + c + ch, k1);
         ldp<VN>(coef + 2 * c + ch, k2);
+        const typename Elt<T>::S* dp = dy + dy_off + ch;
+        const typename Elt<T>::S* zp = z + z_off + ch;
+        typename Elt<T>::S* op = dz + dz_off + ch;
+        auto emit = [&](int p, const float (&d)[VN], const float (&x)[VN]) {
+            float o[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const float xc = x[e] - mu[e];
-            const float du = d[e] * act_grad_c<ACT>(xc * sc[e] + sh[e]);
-            o[e] = k0[e] * (du - k1[e] - xc * is[e] * k2[e]);
+            for (int e = 0; e < VN; ++e) {
+                const float xc = x[e] - mu[e];
+                const float du = d[e] * act_grad_c<ACT>(xc * sc[e] + sh[e]);
+                o[e] = k0[e] * (du - k1[e] - xc * is[e] * k2[e]);
+            }
+            Vec16<T>::st(op + (size_t)p * dz_ld, o);
+        };
+        constexpr int NP = AP_MLP / 2;
+        int p = p0 + lane;
+        for (; p + (NP - 1) * g.lanes < p1; p += NP * g.lanes) {
+            float d[NP][VN], x[NP][VN];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                Vec16<T>::ld(dp + (size_t)(p + u * g.lanes) * dy_ld, d[u]);
+                Vec16<T>::ld(zp + (size_t)(p + u * g.lanes) * z_ld, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) emit(p + u * g.lanes, d[u], x[u]);
         }
-        Vec16<T>::st(dz + (size_t)p * dz_ld + dz_off + ch, o);
+        for (; p < p1; p += g.lanes) {
+            float d[VN], x[VN];
+            Vec16<T>::ld(dp + (size_t)p * dy_ld, d);
+            Vec16<T>::ld(zp + (size_t)p * z_ld, x);
+            emit(p, d, x);
+        }
     }
 }
 
@@ -420,6 +481,20 @@ static int red_blocks(int m, int c, int vn, int* pix_per_block, bool* long_run) 
     ppb = (m + nblk - 1) / nblk;
     *pix_per_block = ppb;
     if (long_run) *long_run = ppb / lanes > 256;
+    return (m + ppb - 1) / ppb;
+}
+
+// Blocks of the apply passes: AP_RUN pixels per thread, at most 8192 blocks
+constexpr int AP_RUN = 8;
+static int ap_blocks(int m, int c, int vn, int* pix_per_block) {
+    const int cv = c / vn;
+    const int lanes = 256 / (cv < 256 ? cv : 256);
+    int ppb = AP_RUN * lanes;
+    int nblk = (m + ppb - 1) / ppb;
+    if (nblk > 8192) nblk = 8192;
+    if (nblk < 1) nblk = 1;
+    ppb = (m + nblk - 1) / nblk;
+    *pix_per_block = ppb;
     return (m + ppb - 1) / ppb;
 }
 
@@ -472,11 +547,14 @@ int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const
         return fail(YOLO_ERR_ARG, "bn_act_fwd: channel counts / strides must be multiples of %d", vn);
     if (out_mode != YOLO_OUT_NHWC && out_mode != YOLO_OUT_UPSAMPLE2X) return fail(YOLO_ERR_ARG, "bn_act_fwd: out_mode");
     const long long m = (long long)n * h * w;
+    if (m > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "bn_act_fwd: too many pixels");
+    int ppb;
+    const int nblk = ap_blocks((int)m, c, vn, &ppb);
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_fwd",
         YOLO_SWITCH_ACT(act,
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(ew_grid(m * (c / vn))), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z,
-                               z_ld, z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, m, c, h, w,
-                               out_mode, nan_flag)));
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const Elt<T>::S*)z,
+                               z_ld, z_off, mean, scale, shift, (const Elt<T>::S*)residual, r_ld, r_off, (Elt<T>::S*)y, y_ld, y_off, (int)m, c, h, w,
+                               out_mode, ppb, nan_flag)));
     return check_launch("bn_act_fwd");
 }
 
@@ -507,10 +585,12 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, s, part, nblk, m, c, gamma, mean, invstd, dgamma, dbeta, coef);
     rc = check_launch("bn_bwd_finalize");
     if (rc || !gamma) return rc;
+    int appb;
+    const int anblk = ap_blocks(m, c, vn, &appb);
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
         YOLO_SWITCH_ACT(act,
-            hipLaunchKernelGGL((bn_bwd_apply<T, ACT>), dim3(ew_grid((long long)m * (c / vn))), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
-                               (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, (long long)m, c)));
+            hipLaunchKernelGGL((bn_bwd_apply<T, ACT>), dim3(anblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                               (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, m, c, appb)));
     return check_launch("bn_bwd_apply");
 }
 
