@@ -1295,3 +1295,69 @@ def test_batched_weight_pack_equals_per_layer_pack(yt, dtype):
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(zip(single, batch)):
             assert torch.equal(a, b), (dgrad, i, shapes[i])
+
+
+# ------------------------------------------------------------- the LDS-DMA 16-bit kernels at their edges (tile 8 forced)
+DMA_CASES = [
+    # (B, H, cin, cout, k, residual, act, upsample, x_ld, x_off, y_ld, y_off)
+    (2, 13, 128, 128, 1, False, 1, False, 128, 0, 128, 0),     # 1x1, KT = 4: only the peeled last group runs
+    (1, 19, 160, 136, 1, False, 2, False, 160, 0, 136, 0),     # KT = 5 (ring wraps once), cout not a multiple of 128, ragged pixel tile
+    (3, 26, 384, 256, 1, False, 1, False, 512, 64, 768, 256),  # reads a slice of a concat buffer, writes into one
+    (2, 13, 256, 128, 1, False, 1, True, 256, 0, 384, 128),    # the 1x1 in front of nn.Upsample: 2x store into the concat buffer
+    (2, 20, 1024, 512, 1, True, 0, False, 1024, 0, 512, 0),    # 32 K steps, identity epilogue + residual = the 1x1 input gradient
+    (2, 13, 128, 256, 3, True, 1, False, 128, 0, 256, 0),      # 3x3 residual block tail
+    (1, 19, 96, 128, 3, False, 2, False, 96, 0, 128, 0),       # three 32-channel chunks (odd), odd grid width
+    (2, 26, 64, 136, 3, False, 0, False, 64, 0, 136, 0),       # two chunks, cout not a multiple of 128
+    (5, 7, 256, 128, 3, False, 1, True, 256, 0, 128, 0),       # tiles straddle images, 2x upsampling store
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_dma_conv_kernels_edge_shapes(yt, case, dtype):
+    """conv3_dma_h16 / conv1_dma_h16 called through the C-ABI with `tile = 8` on the shapes their index math can get wrong
+    (ring wrap-around, peeled last group, ragged tiles, image-straddling tiles, channel counts that are not tile multiples,
+    ld / off views of concat buffers, the 2x-upsampling store, residual accumulate). Reference: fp64 convolution of the SAME
+    rounded operands on the CPU, so the only error left is fp32 accumulation order + the final rounding."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, cin, cout, k, residual, act, upsample, x_ld, x_off, y_ld, y_off = case
+    code, tdt, tol = {"bf16": (L.BF16, torch.bfloat16, 1e-2), "fp16": (L.F16, torch.float16, 2e-3)}[dtype]
+    g = torch.Generator().manual_seed(1000 + 7 * cin + cout + k)
+    lib, dev = L.lib(), torch.device("cuda:0")
+    x = torch.randn((B, H, H, x_ld), generator=g).to(tdt)
+    w = (torch.randn((cout, cin, k, k), generator=g) * (1.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    Ho = 2 * H if upsample else H
+    y0 = torch.randn((B, Ho, Ho, y_ld), generator=g).to(tdt)                    # what is NOT written must survive
+    r = torch.randn((B, H, H, cout), generator=g).to(tdt) if residual else None
+    xd, yd, sd, shd = x.to(dev), y0.clone().to(dev), scale.to(dev), shift.to(dev)
+    rd = r.to(dev) if residual else None
+    wd = w.to(dev)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, k, code), dtype=torch.uint8, device=dev)
+    st = L.current_stream()
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, k, code, st))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=1, x_ld=x_ld, x_off=x_off, y_ld=y_ld, y_off=y_off, r_ld=cout, r_off=0,
+                   act=act, out_mode=L.OUT_UPSAMPLE2X if upsample else L.OUT_NHWC, dtype=code,
+                   flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=8)
+    L.check(lib.yolo_conv_fwd(d, xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                              yd.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    xin = x[..., x_off:x_off + cin].double().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.to(tdt).double(), stride=1, padding=k // 2)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.1) if act == 1 else (F.mish(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + r.double()
+    if upsample:
+        ref = ref.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    got = yd.cpu()
+    err = float((got[..., y_off:y_off + cout].double() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err
+    keep = torch.ones(y_ld, dtype=torch.bool)
+    keep[y_off:y_off + cout] = False
+    assert torch.equal(got[..., keep], y0[..., keep])                           # neighbouring channels of the buffer untouched
