@@ -148,30 +148,72 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs p) {
 // dW (OIHW) = sum over slices, fixed order. Threads walk the PARTIAL layout ([co][tap][ci], ci fastest) four ci at a
 // time: every slice is read with coalesced 16-byte loads (the first version walked the OIHW output order and read the
 // slices with a stride of cin_pad floats — 2.1 TB/s on 75 MB per layer); the 4-byte OIHW writes are 1/nslices of the bytes.
+// G lanes share one output vector: lane g adds slices g, g + G, ... (two chains), the G lane sums are added in lane order
+// through LDS. G = 1 for big weight tensors (enough vectors to fill the chip); G = 16 for the small ones, where one thread
+// walking 256-512 slices serially took 35-41 us for a few KB of output. The order depends only on (nslices, G): deterministic.
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int nslices, int cout, int cin,
                                                     int cin_pad, int taps, int cout_pad, long long total4) {
     const size_t slice = (size_t)cout_pad * taps * cin_pad;
     const int c4n = cin_pad >> 2;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        const long long r = i / c4n;
-        const int t = (int)(r % taps);
-        const int co = (int)(r / taps);
-        const float* src = partial + ((size_t)co * taps + t) * cin_pad + c4 * 4;
+    __shared__ f32x4 red[256];
+    const long long nthreads = total4 * G;
+    for (long long base = blockIdx.x * 256LL; base < nthreads; base += (long long)gridDim.x * 256) {
+        const long long id = base + threadIdx.x;
+        const long long i = id / G;
+        const int g = (int)(id - i * G);
+        const bool live = id < nthreads;
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-        int k = 0;
-        for (; k + 1 < nslices; k += 2) {                 // two independent chains, order fixed: (0+2+4..) + (1+3+5..)
-            s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * slice);
-            s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * slice);
+        int c4 = 0, t = 0, co = 0;
+        if (live) {
+            c4 = (int)(i % c4n);
+            const long long r = i / c4n;
+            t = (int)(r % taps);
+            co = (int)(r / taps);
+            const float* src = partial + ((size_t)co * taps + t) * cin_pad + c4 * 4;
+            int k = g;
+            for (; k + G < nslices; k += 2 * G) {             // two independent chains, order fixed
+                s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * slice);
+                s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + G) * slice);
+            }
+            if (k < nslices) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * slice);
+            s0 += s1;
         }
-        if (k < nslices) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * slice);
-        s0 += s1;
+        if (G > 1) {
+            __syncthreads();
+            red[threadIdx.x] = s0;
+            __syncthreads();
+            if (g == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ci = c4 * 4 + e;
-            if (ci < cin) dw[((size_t)co * cin + ci) * taps + t] = s0[e];
+                for (int l = 1; l < G; ++l) s0 += red[threadIdx.x + l];
+            }
+        }
+        if (live && g == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = c4 * 4 + e;
+                if (ci < cin) dw[((size_t)co * cin + ci) * taps + t] = s0[e];
+            }
         }
     }
+}
+
+static int launch_wgrad_reduce(const float* partial, float* dw, int nslices, int cout, int cin, int cin_pad, int taps, int cout_pad,
+                               long long total4, hipStream_t s) {
+    // vectors x lanes >= ~64k threads: the small tensors of the high-resolution layers have 128-512 slices and < 10k vectors
+    if (total4 < 16384 && nslices >= 32) {
+        const long long nt = total4 * 16;
+        const int grid = (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
+        hipLaunchKernelGGL(wgrad_reduce<16>, dim3(grid), dim3(256), 0, s, partial, dw, nslices, cout, cin, cin_pad, taps, cout_pad, total4);
+    } else if (total4 < 65536 && nslices >= 8) {
+        const long long nt = total4 * 4;
+        const int grid = (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
+        hipLaunchKernelGGL(wgrad_reduce<4>, dim3(grid), dim3(256), 0, s, partial, dw, nslices, cout, cin, cin_pad, taps, cout_pad, total4);
+    } else {
+        const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(wgrad_reduce<1>, dim3(grid), dim3(256), 0, s, partial, dw, nslices, cout, cin, cin_pad, taps, cout_pad, total4);
+    }
+    return check_launch("wgrad_reduce");
 }
 
 struct WgradPlan { int bm, bn, smallc, tiles_m, tiles_n, tiles_per_tap, total_steps, nslices, steps_per_slice, cout_pad, kp; };
@@ -239,15 +281,12 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
         return fail(YOLO_ERR_ARG, "wgrad: ld/off must be multiples of 4 and cover the padded channels");
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)cout * ksize * ksize * (cp / 4);            // float4 groups of the partial layout
-    const int rgrid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype != YOLO_F32 && wgrad_h16_eligible(cin, cout, ksize, stride, dz_ld, dz_off, x_ld, x_off)) {
         int cout_pad = 0;
         const int ns = wgrad_h16_launch(dz, dz_ld, dz_off, x, x_ld, x_off, (float*)workspace, n, h, w, cin, cout, ksize, stride, dtype,
                                         &cout_pad, s);
         if (ns < 0) return ns;
-        hipLaunchKernelGGL(wgrad_reduce, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw_oihw, ns, cout, cin, cp,
-                           ksize * ksize, cout_pad, total);
-        return check_launch("wgrad_reduce");
+        return launch_wgrad_reduce((const float*)workspace, dw_oihw, ns, cout, cin, cp, ksize * ksize, cout_pad, total, s);
     }
     const WgradPlan q = plan_wgrad(n, h, w, cin, cout, ksize, stride);
     WgradArgs a;
@@ -271,9 +310,7 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
         else hipLaunchKernelGGL((wgrad_f32_kernel<T, 64, 64, false>), grid, block, 0, s, a));
     int rc = check_launch("wgrad_f32");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw_oihw, q.nslices, cout, cin, cp,
-                       ksize * ksize, q.cout_pad, total);
-    return check_launch("wgrad_reduce");
+    return launch_wgrad_reduce((const float*)workspace, dw_oihw, q.nslices, cout, cin, cp, ksize * ksize, q.cout_pad, total, s);
 }
 
 }  // extern "C"

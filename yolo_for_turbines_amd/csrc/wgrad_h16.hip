@@ -267,7 +267,8 @@ static WgradHPlan plan_wgrad_h(int n, int h, int w, int cin, int cout, int ks, i
     int maxs = ceil_div(q.total_tiles, 8);                  // at least 8 K tiles per slice
     if (maxs < 1) maxs = 1;
     int ns = want < 1 ? 1 : (want > maxs ? maxs : want);
-    if (ns > 256) ns = 256;
+    if (ns > 512) ns = 512;                                 // (was 256: the one-tile layers - stem, 32->64 - then ran ONE block per CU and
+                                                            //  streamed their 350 MB of dz at 0.66 TB/s: 537 us each)
     if (ns >= 8) ns = ns / 8 * 8;                           // multiples of 8: XCD-aware block mapping
     q.tiles_per_slice = ceil_div(q.total_tiles, ns);
     q.nslices = ns;                                         // trailing slices may be empty (they write zeros)
