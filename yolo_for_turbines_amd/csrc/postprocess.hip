@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 namespace yolo {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------ decode
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
@@ -264,42 +265,73 @@ __device__ __forceinline__ unsigned long long suppression_word(const SBox& me, b
                                                               float thr) {
     unsigned long long word = 0;
     if (TAME) {
-        // four columns per step (cols[] has 64 entries; those at or beyond lim are masked out): four independent LDS reads
-        // and IoU chains in flight, one class test and one "needs the division" test per step
+        // Two passes. (1) all 64 columns, ~10 instructions per pair: CANDIDATE = same class and the boxes overlap in x and in y
+        // (strictly positive width and height of the intersection). Every other same-class pair has inter = +-0 exactly, and with
+        // den = (a1 + a2) + 1e-6 > 0 (checked per pair) its iou is +-0: it suppresses iff !(0 < thr), decided once per word.
+        // (2) the exact IoU with the IEEE division only for the candidates, each lane walking the set bits of ITS word: with
+        // 2 classes and 10,000 boxes 3 % of the pairs are candidates (~2 per word, ~7 for the busiest lane of a wave), so
+        // the division work drops ~8x; the old single pass divided whenever ANY of a wave's 256 pairs intersected - always.
         const bool zero_suppresses = !(0.f < thr);        // iou == +-0 for a pair that does not intersect
-        for (int j0 = 0; j0 < lim; j0 += 4) {
-            bool same[4];
-            bool any_same = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                same[u] = active && j0 + u < lim && cols[j0 + u].cls == me.cls;
-                any_same |= same[u];
+        unsigned clo = 0, chi = 0, slo = 0, shi = 0;      // candidate bits / same-class-and-zero-iou bits, low and high 32 columns
+        auto half = [&](int j0, unsigned& cbits, unsigned& sbits) {
+#pragma unroll 8
+            for (int jj = 0; jj < 32; ++jj) {             // branch-free: bitwise & / | on the predicates, all six fields read up front
+                const f32x4 c = *reinterpret_cast<const f32x4*>(&cols[j0 + jj].x1);    // entries at or beyond lim are masked out below
+                const f32x2 ac = *reinterpret_cast<const f32x2*>(&cols[j0 + jj].area); // area, cls
+                const bool same = ac[1] == me.cls;
+                const float xa = vmax(me.x1, c[0]), ya = vmax(me.y1, c[1]);
+                const float xb = vmin(me.x2, c[2]), yb = vmin(me.y2, c[3]);
+                const bool den_bad = !((me.area + ac[0]) + 1e-6f > 0.f);               // ((a1 + a2) - 0) + 1e-6, the pair's denominator
+                const bool cand = same & (((xb > xa) & (yb > ya)) | den_bad);
+                const unsigned bit = 1u << jj;
+                cbits |= cand ? bit : 0u;
+                sbits |= same ? bit : 0u;
             }
-            if (__ballot(any_same) == 0ull) continue;       // no row of this wave shares a class with these columns
-            float inter[4], den[4];
-            bool need = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const SBox o = cols[j0 + u];
+        };
+        // the common column block: every row and column of one class and every area positive (so the denominator of a
+        // non-intersecting pair is positive) - 4 min/max + 2 compares per pair and nothing else
+        auto half_uni = [&](int j0, unsigned& cbits) {
+#pragma unroll 8
+            for (int jj = 0; jj < 32; ++jj) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(&cols[j0 + jj].x1);
+                const float xa = vmax(me.x1, c[0]), ya = vmax(me.y1, c[1]);
+                const float xb = vmin(me.x2, c[2]), yb = vmin(me.y2, c[3]);
+                cbits |= ((xb > xa) & (yb > ya)) ? (1u << jj) : 0u;
+            }
+        };
+        const int lane_c = (int)(threadIdx.x & 63);
+        const bool odd = (active && !(me.area > 0.f)) || (lane_c < lim && !(cols[lane_c].area > 0.f)) ||
+                         (active && cols[0].cls != me.cls) || (lane_c < lim && cols[lane_c].cls != cols[0].cls);
+        if (__ballot(odd) == 0ull) {
+            half_uni(0, clo);
+            half_uni(32, chi);
+            slo = shi = ~0u;
+        } else {
+            half(0, clo, slo);
+            half(32, chi, shi);
+        }
+        const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+        unsigned long long cw = ((((unsigned long long)chi) << 32) | clo) & valid;
+        const unsigned long long sw = ((((unsigned long long)shi) << 32) | slo) & valid;
+        if (!active) cw = 0ull;
+        word = (active && zero_suppresses) ? (sw & ~cw) : 0ull;
+        while (__ballot(cw != 0ull)) {                    // wave-uniform trip count: the busiest lane's candidates
+            if (cw) {
+                const int jj = __builtin_ctzll(cw);
+                cw &= cw - 1ull;
+                const SBox o = cols[jj];
                 const float xa = vmax(me.x1, o.x1), ya = vmax(me.y1, o.y1);
                 const float xb = vmin(me.x2, o.x2), yb = vmin(me.y2, o.y2);
                 const float iw = vmax(xb - xa, 0.f), ih = vmax(yb - ya, 0.f);
-                inter[u] = iw * ih;
-                den[u] = ((me.area + o.area) - inter[u]) + 1e-6f;
-                need |= same[u] && !(inter[u] == 0.f && den[u] > 0.f);
-            }
-            if (__ballot(need) == 0ull) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (same[u] && zero_suppresses && col0 + j0 + u > i) word |= 1ull << (j0 + u);
-                continue;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float iou = inter[u] / den[u];
-                if (same[u] && !(iou < thr) && col0 + j0 + u > i) word |= 1ull << (j0 + u);
+                const float inter = iw * ih;
+                const float den = ((me.area + o.area) - inter) + 1e-6f;
+                const float iou = inter / den;
+                if (!(iou < thr)) word |= 1ull << jj;
             }
         }
+        // only columns after row i
+        const int first = i + 1 - col0;                   // first admissible bit
+        if (first > 0) word &= first >= 64 ? 0ull : (~0ull << first);
         return word;
     }
     for (int jj = 0; jj < lim; ++jj) {
@@ -739,6 +771,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
 // loop (the per-image chain of ~160 row blocks becomes ~10 per wave at 80 classes; with 2 classes two waves work).
 // A 64-row block that straddles a cut is visited by both neighbours, each with its own row mask. Kept rows are reported
 // as bits of keptw (atomicOr: straddling blocks) and placed in output order by nms_place_kernel.
+constexpr int SCAN_MLP = 8;
 __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned long long* __restrict__ mask,
                                                                const unsigned long long* __restrict__ sorted2,
                                                                const int* __restrict__ nvalid, const unsigned long long* __restrict__ row_any,
@@ -818,17 +851,18 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
                 for (int c = rb + 1 + lane; c <= rb1; c += 64) {
                     if (lo[c] > hi_r) break;            // never written: classes above this row block's
                     unsigned long long acc = 0ull, wk = work;
-                    while (wk) {                        // four rows' words in flight (a spent slot repeats the last row)
-                        int t[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                    while (wk) {                        // SCAN_MLP rows' words in flight (a spent slot repeats the last row): the
+                        int t[SCAN_MLP];                // mask is MALL / HBM-resident, ~40 kept rows per block, and with 4 in flight
+#pragma unroll                                          // the 79 row blocks of a 5,000-box class cost 10 round trips each
+                        for (int u = 0; u < SCAN_MLP; ++u) {
                             t[u] = wk ? __builtin_ctzll(wk) : t[u ? u - 1 : 0];
                             wk &= wk - 1ull;
                         }
-                        unsigned long long w4[4];
+                        unsigned long long wv[SCAN_MLP];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) w4[u] = mk[(size_t)(rb * 64 + t[u]) * W + c];
-                        acc |= (w4[0] | w4[1]) | (w4[2] | w4[3]);
+                        for (int u = 0; u < SCAN_MLP; ++u) wv[u] = mk[(size_t)(rb * 64 + t[u]) * W + c];
+#pragma unroll
+                        for (int u = 0; u < SCAN_MLP; ++u) acc |= wv[u];
                     }
                     if (acc) removed[c] |= acc;         // this lane owns word c of this wave's array
                 }
