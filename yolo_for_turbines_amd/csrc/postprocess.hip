@@ -845,22 +845,26 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
             const unsigned long long kept = rowmask & ~rem;
             count += __popcll(kept);
             if (lane == 0 && kept) atomicOr(&keptw[(size_t)b * W + rb], kept);
-            const unsigned long long work = kept & any_rb;  // kept rows with a bit in some later column block
+            const unsigned long long work_v = kept & any_rb;  // kept rows with a bit in some later column block
+            // wave-uniform by construction; said so to the compiler, which otherwise walks the row bits with ~12 VALU
+            // instructions + a 64-bit multiply per row and lane. Scalar: s_ff1 / s_andn2 per row, the row base in SGPRs and
+            // the lane's column as the 32-bit offset of the load.
+            const unsigned long long work = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(work_v >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)work_v);
             if (work) {
                 const int hi_r = hi[rb];
-                for (int c = rb + 1 + lane; c <= rb1; c += 64) {
+                const unsigned long long* blkp = mk + (size_t)rb * 64 * W;
+                for (unsigned c = (unsigned)(rb + 1 + lane); (int)c <= rb1; c += 64) {
                     if (lo[c] > hi_r) break;            // never written: classes above this row block's
                     unsigned long long acc = 0ull, wk = work;
-                    while (wk) {                        // SCAN_MLP rows' words in flight (a spent slot repeats the last row): the
-                        int t[SCAN_MLP];                // mask is MALL / HBM-resident, ~40 kept rows per block, and with 4 in flight
-#pragma unroll                                          // the 79 row blocks of a 5,000-box class cost 10 round trips each
-                        for (int u = 0; u < SCAN_MLP; ++u) {
-                            t[u] = wk ? __builtin_ctzll(wk) : t[u ? u - 1 : 0];
-                            wk &= wk - 1ull;
-                        }
+                    int tl = 0;
+                    while (wk) {                        // SCAN_MLP rows' words in flight (a spent slot repeats the last row)
                         unsigned long long wv[SCAN_MLP];
 #pragma unroll
-                        for (int u = 0; u < SCAN_MLP; ++u) wv[u] = mk[(size_t)(rb * 64 + t[u]) * W + c];
+                        for (int u = 0; u < SCAN_MLP; ++u) {
+                            if (wk) { tl = __builtin_ctzll(wk); wk &= wk - 1ull; }
+                            wv[u] = blkp[(size_t)tl * W + c];
+                        }
 #pragma unroll
                         for (int u = 0; u < SCAN_MLP; ++u) acc |= wv[u];
                     }
