@@ -2137,7 +2137,11 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     if (d->tile == 8 && !dma_ok && !dma1_ok)
         return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 8 needs 3x3 stride 1 with more than 64 output channels, or 1x1 with >= 128 input and output channels");
     const bool use_dma = dma_ok && (d->tile >= 8 || (d->tile == 0 && g_h_dma));
-    a.qperm = d->tile == 10 ? 0x76452310u : 0x76543210u;
+    // lane quad -> pixel quad of a 32-pixel m-tile. Identity makes every patch ds_read_b128 2-way bank-conflicted with the 32x4
+    // pixel tiles of 52x52 / 104x104 (its two 16-lane groups are quads {0,3,5,6} and {1,2,4,7}: 4 rows whose patch offsets collide
+    // mod 16); sending even tile rows to one group and odd rows to the other removes that, and measured 1-4 % at every size
+    // (profiles/r02/ab_quad_permutation.txt). Tile 10 keeps the identity map for A/B.
+    a.qperm = d->tile == 10 ? 0x76543210u : 0x76452310u;
     a.cls_ph = (d->tile == 0 && g_h_dma_persist) ? 11 : d->tile;
     if (dma1_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma))) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
