@@ -54,6 +54,41 @@ def test_config2_batch32_416_fp32(yt, golden):
         assert torch.isfinite(pa).all()
 
 
+@pytest.mark.parametrize("dtype,B,S", [("bf16", 32, 416), ("fp16", 16, 608)])
+def test_config4_5_16bit_forward_full_size(yt, golden, dtype, B, S):
+    """BASELINE configs[3-4] arithmetic at their full per-GPU sizes (bf16 batch 32 at 416x416; fp16 batch 16 at 608x608,
+    `/root/reference/code/demo.py:33-51` under autocast): the 16-bit kernels (conv3_dma_h16 / conv1_dma_h16 / conv_patch_h16)
+    with grids of several resident rounds, tiles that straddle images and block counts that are not multiples of the 8 XCDs.
+    Image 17 (5) of the batch is bit-equal to its batch-1 run, two runs are bitwise identical, and at 416x416 the batch-1 run is
+    the golden-checked image within the 16-bit network tolerance."""
+    name = "nc80_s416_b1_leaky"
+    c = gi.NET_CASES[name]
+    m = yt.YOLOv3(num_classes=c["nc"], activation=c["act"])
+    m.load_state_dict(onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN))
+    m = m.cuda().eval()
+    m._engine.compute_dtype = dtype
+    k = 17 if B > 17 else 5
+    x = torch.rand((B, 3, S, S), generator=torch.Generator().manual_seed(3))
+    if S == c["size"]:
+        x[k] = onet.synth_input(c["xseed"], 1, S)[0]
+    x = x.cuda()
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)
+        single = m(x[k:k + 1].contiguous())
+    g = golden("net_fwd")
+    for i, (pa, pb, ps) in enumerate(zip(a, b, single)):
+        assert pa.shape == (B, 3, S // (32 >> i), S // (32 >> i), 85)
+        assert torch.isfinite(pa).all()
+        assert torch.equal(pa, pb)
+        assert torch.equal(pa[k:k + 1], ps)
+        if S == c["size"]:
+            ref = g[f"{name}/p{i}_sample"]
+            got = ps.reshape(-1).cpu()[::gi.SAMPLE_STRIDE].float().numpy()
+            tol = {"bf16": 1.2e-1, "fp16": 2e-2}[dtype] * max(1.0, float(np.abs(ref).max()))
+            assert float(np.abs(got - ref).max()) <= tol
+
+
 @pytest.mark.parametrize("S", [608, 320])
 def test_config3_batch64_bf16_train_step(yt, S):
     nc, B = 2, 64
