@@ -15,6 +15,7 @@ epilogues — no separate add / slice / concat kernels.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -41,6 +42,9 @@ def _desc(B, x: TView, cin, cout, k, s, y_ld, y_off, r: TView = None, act=L.ACT_
         d.r_ld, d.r_off = r.ld, r.off
         d.flags |= L.FLAG_RESIDUAL
     return d
+
+
+_WGRAD_OVERLAP = os.environ.get("YOLO_WGRAD_OVERLAP", "1") != "0"      # A/B switch: weight gradients on a side stream
 
 
 class TrainPlan:
@@ -247,11 +251,39 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
     for b, t in (seeds or {}).items():
         G.state[b] = ("own", t)
     dz_scratch = {}
+    # Weight gradients on a SIDE stream (single GPU): wgrad + its split-K reduce only feed the optimizer, while the chain
+    # dz -> dgrad -> BatchNorm backward of the previous block is what the next block waits for. The BatchNorm passes and the
+    # reduce are HBM-bound, the convolutions matrix-bound, so the two streams complement each other on the CUs. dz scratch
+    # buffers then rotate in pairs: a buffer is rewritten only after the wgrad that read it has finished (event), and the
+    # main stream joins the side stream before this function returns (allocator reuse stays stream-ordered). With gradient
+    # buckets (data parallel) everything stays on one stream: the all-reduce hooks are ordered against it.
+    # Measured (bf16, B=32, 416^2): eager 22.8 -> 21.0 ms (fp32 80.0 -> 76.2): the second stream mostly fills the launch gaps of
+    # the first. Replayed as ONE HIP graph there are no gaps and the concurrent kernels only disturb each other (19.0 -> 19.7
+    # ms), so a capture keeps everything on one stream.
+    overlap = buckets is None and _WGRAD_OVERLAP and not torch.cuda.is_current_stream_capturing()
+    main_s = torch.cuda.current_stream()
+    side_s = None
+    if overlap:
+        side_s = getattr(plan, "side_stream", None)
+        if side_s is None:
+            side_s = plan.side_stream = torch.cuda.Stream(device=dev)
+    busy = {}                                                          # id(scratch tensor) -> event of its last side-stream reader
+    rot = {}
 
     def scratch(numel):
-        t = dz_scratch.get(numel)
+        if not overlap:
+            t = dz_scratch.get(numel)
+            if t is None:
+                t = dz_scratch[numel] = torch.empty(numel, dtype=plan.tdtype, device=dev)
+            return t
+        k = rot.get(numel, 0)
+        rot[numel] = k ^ 1
+        t = dz_scratch.get((numel, k))
         if t is None:
-            t = dz_scratch[numel] = torch.empty(numel, dtype=plan.tdtype, device=dev)
+            t = dz_scratch[(numel, k)] = torch.empty(numel, dtype=plan.tdtype, device=dev)
+        ev = busy.pop(id(t), None)
+        if ev is not None:
+            main_s.wait_event(ev)
         return t
 
     # Frozen backbone (`freeze=True`, model.py:306-309,330-334): nothing below the first block that owns a trainable
@@ -340,8 +372,19 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
         # ---------------------------------------------------------------- wgrad
         if need.get(id(cv.weight), False):
             dw = new_grad(cv.weight)
+            wstream = stream
+            if overlap:
+                e_dz = torch.cuda.Event()
+                e_dz.record(main_s)
+                side_s.wait_event(e_dz)
+                dw.record_stream(side_s)
+                wstream = side_s.cuda_stream
             L.check(lib.yolo_conv_wgrad(dz.data_ptr(), dz_ld, 0, plan.view_ptr(xv), xv.ld, xv.off, dw.data_ptr(), B, xv.H, xv.W, cin,
-                                        cout, k, s, code, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), stream), "yolo_conv_wgrad")
+                                        cout, k, s, code, plan.wg_ws.data_ptr(), plan.wg_ws.numel(), wstream), "yolo_conv_wgrad")
+            if overlap:
+                e_w = torch.cuda.Event()
+                e_w.record(side_s)
+                busy[id(dz)] = e_w
             grads[id(cv.weight)] = dw
             done(cv.weight)
         # ---------------------------------------------------------------- dgrad into the input's gradient
@@ -374,6 +417,8 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             G.release(yv.buf)
         elif yv is not None and op["out_mode"] == L.OUT_UPSAMPLE2X and not _shared_later(prog, i, yv.buf):
             G.release(yv.buf)
+    if overlap:
+        main_s.wait_stream(side_s)                                     # join: every gradient is ready in main-stream order
     gin = G.state.get(prog.input.buf)
     return grads, (gin[1] if (want_input_grad and gin is not None and gin[0] == "own") else None)
 
