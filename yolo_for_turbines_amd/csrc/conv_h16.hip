@@ -1758,6 +1758,59 @@ __global__ void pack_batch_h16(const PackBatchH b) {
     }
 }
 
+// The same conversion one 32 x 32 x taps CELL per block: the rows of a cell are contiguous runs of 32 * taps floats in the
+// OIHW tensor (forward: one output channel's 32 input channels; dgrad: one output channel's 32 input channels read as the
+// GEMM's n), so they are read with 16-byte loads, rounded once, parked in LDS and written out in fragment order with one
+// 16-byte store per (tap, half, lane). The element-wise kernel above reads 4 bytes at a stride of taps * 4 (and a 64-bit
+// divide) per element: 2 x ~100 us per fine-tune step for the forward layouts and as much again for the gradient layouts.
+// Needs cin % 32 == 0 (row alignment); other items keep the element-wise kernel.
+template <typename T, bool DGRAD>
+__global__ __launch_bounds__(256) void pack_batch_tiled_h16(const PackBatchH b) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[32][32 * 9 + 8];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.it[k + 1].first_block) ++k;
+    const PackItemH& q = b.it[k];
+    const int taps = q.ks * q.ks;
+    const int chunks = q.KT / taps;
+    const int cell = (int)blockIdx.x - q.first_block;
+    const int nt = cell / chunks, chunk = cell - nt * chunks;
+    const int run = 32 * taps;                                       // floats per row of the cell
+    const int tid = threadIdx.x;
+    // rows: forward = output channel a (n of the GEMM), columns (ci_local, tap); dgrad = output channel c (k of the GEMM),
+    // columns (ci_local = n of the GEMM, source tap)
+    {
+        const int r = tid >> 3, part = tid & 7;                      // 8 threads per row
+        const int row_ch = (DGRAD ? chunk : nt) * 32 + r;            // output channel of this row
+        const int col0 = (DGRAD ? nt : chunk) * 32;                  // first input channel of the run
+        const bool row_ok = row_ch < q.cout && col0 < q.cin;
+        const float* src = q.w + ((size_t)row_ch * q.cin + col0) * taps;
+        const int avail = row_ok ? ((q.cin - col0 < 32 ? q.cin - col0 : 32) * taps) : 0;   // floats of the run that exist
+        for (int f = part * 4; f < run; f += 32) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f + 3 < avail) v = *reinterpret_cast<const f32x4*>(src + f);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (f + e < avail) v[e] = src[f + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][f + e] = HTraits<T>::from_f32(v[e]);
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < taps * 128; w += 256) {                    // (tap, s, lane): one 16-byte store each
+        const int lane = w & 63, s2 = (w >> 6) & 1, tap = w >> 7;
+        const int al = lane & 31, cl = s2 * 16 + 8 * (lane >> 5);
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = DGRAD ? tile[cl + e][al * taps + (taps - 1 - tap)] : tile[al][(cl + e) * taps + tap];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (unsigned)h[2 * e] | ((unsigned)h[2 * e + 1] << 16);
+        const size_t idx = (((size_t)nt * q.KT + (size_t)chunk * taps + tap) * 2 + s2) * 512 + (size_t)lane * 8;
+        *reinterpret_cast<u32x4*>(q.wf + idx) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 static const bool g_h_stagger = !(getenv("YOLO_NO_STAGGER"));
 static const bool g_h_dma = !(getenv("YOLO_NO_DMA"));
@@ -1802,36 +1855,58 @@ int h16_pack_dgrad(const float* w_oihw, void* wf, int cout, int cin, int ks, int
 // items: host array. dgrad = 1: the flipped / transposed stride-1 input-gradient weights (h16_pack_dgrad layout)
 int h16_pack_batch(const float* const* w, void* const* wf, const int* cout, const int* cin, const int* ks, int n, int dgrad, int dtype,
                    hipStream_t s) {
-    for (int base = 0; base < n; base += H_PACK_BATCH) {
-        PackBatchH b;
-        b.n = n - base < H_PACK_BATCH ? n - base : H_PACK_BATCH;
-        int blocks = 0;
-        for (int j = 0; j < b.n; ++j) {
-            const int i = base + j;
-            PackItemH& q = b.it[j];
-            q.w = w[i]; q.wf = (unsigned short*)wf[i]; q.cout = cout[i]; q.cin = cin[i]; q.ks = ks[i];
-            if (dgrad) {
-                const int coutp = round_up(cout[i], 32);
-                q.total = (long long)h16_frag_elems(cin[i], coutp, ks[i]);
-                q.KT = (coutp / 32) * ks[i] * ks[i];
-            } else {
-                q.total = (long long)h16_frag_elems(cout[i], cin[i], ks[i]);
-                q.KT = (round_up(cin[i], 32) / 32) * ks[i] * ks[i];
+    // two passes over the items: those whose rows are 16-byte aligned runs (cin % 32 == 0) go to the tiled kernel, one cell
+    // per block; the rest (the 3-channel stem) to the element-wise one
+    for (int tiled = 1; tiled >= 0; --tiled) {
+        int base = 0;
+        while (base < n) {
+            PackBatchH b;
+            b.n = 0;
+            int blocks = 0;
+            for (; base < n && b.n < H_PACK_BATCH; ++base) {
+                const int i = base;
+                const bool can_tile = cin[i] % 32 == 0 && ks[i] * ks[i] <= 9;
+                if (can_tile != (tiled == 1)) continue;
+                PackItemH& q = b.it[b.n++];
+                q.w = w[i]; q.wf = (unsigned short*)wf[i]; q.cout = cout[i]; q.cin = cin[i]; q.ks = ks[i];
+                if (dgrad) {
+                    const int coutp = round_up(cout[i], 32);
+                    q.total = (long long)h16_frag_elems(cin[i], coutp, ks[i]);
+                    q.KT = (coutp / 32) * ks[i] * ks[i];
+                } else {
+                    q.total = (long long)h16_frag_elems(cout[i], cin[i], ks[i]);
+                    q.KT = (round_up(cin[i], 32) / 32) * ks[i] * ks[i];
+                }
+                if (tiled) {
+                    q.nblocks = (int)(q.total / 1024 / (ks[i] * ks[i]));          // cells: n-tiles x 32-channel chunks
+                } else {
+                    const long long nb = (q.total + 255) / 256;
+                    q.nblocks = (int)(nb < 1024 ? nb : 1024);
+                }
+                q.first_block = blocks;
+                blocks += q.nblocks;
             }
-            const long long nb = (q.total + 255) / 256;
-            q.nblocks = (int)(nb < 1024 ? nb : 1024);
-            q.first_block = blocks;
-            blocks += q.nblocks;
+            if (b.n == 0) continue;
+            if (dtype == YOLO_BF16) {
+                if (tiled) {
+                    if (dgrad) hipLaunchKernelGGL((pack_batch_tiled_h16<__bf16, true>), dim3(blocks), dim3(256), 0, s, b);
+                    else hipLaunchKernelGGL((pack_batch_tiled_h16<__bf16, false>), dim3(blocks), dim3(256), 0, s, b);
+                } else {
+                    if (dgrad) hipLaunchKernelGGL((pack_batch_h16<__bf16, true>), dim3(blocks), dim3(256), 0, s, b);
+                    else hipLaunchKernelGGL((pack_batch_h16<__bf16, false>), dim3(blocks), dim3(256), 0, s, b);
+                }
+            } else {
+                if (tiled) {
+                    if (dgrad) hipLaunchKernelGGL((pack_batch_tiled_h16<_Float16, true>), dim3(blocks), dim3(256), 0, s, b);
+                    else hipLaunchKernelGGL((pack_batch_tiled_h16<_Float16, false>), dim3(blocks), dim3(256), 0, s, b);
+                } else {
+                    if (dgrad) hipLaunchKernelGGL((pack_batch_h16<_Float16, true>), dim3(blocks), dim3(256), 0, s, b);
+                    else hipLaunchKernelGGL((pack_batch_h16<_Float16, false>), dim3(blocks), dim3(256), 0, s, b);
+                }
+            }
+            const int rc = check_launch("pack_batch_h16");
+            if (rc) return rc;
         }
-        if (dtype == YOLO_BF16) {
-            if (dgrad) hipLaunchKernelGGL((pack_batch_h16<__bf16, true>), dim3(blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((pack_batch_h16<__bf16, false>), dim3(blocks), dim3(256), 0, s, b);
-        } else {
-            if (dgrad) hipLaunchKernelGGL((pack_batch_h16<_Float16, true>), dim3(blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((pack_batch_h16<_Float16, false>), dim3(blocks), dim3(256), 0, s, b);
-        }
-        const int rc = check_launch("pack_batch_h16");
-        if (rc) return rc;
     }
     return YOLO_OK;
 }
