@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--residual", action="store_true")
+ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (same instruction stream, minimal switching power)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = L.lib()
@@ -30,6 +31,9 @@ for name in a.layer.split(","):
     Ho = (H + 2 * (k // 2) - k) // s + 1
     x = torch.randn(a.batch * H * H * cpad, device=dev).to(tdt)
     w = torch.randn(cout, cin, k, k, device=dev) * (1.0 / (cin * k * k)) ** 0.5
+    if a.zeros:
+        x.zero_()
+        w.zero_()
     wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, k, code), dtype=torch.uint8, device=dev)
     st = L.current_stream()
     L.check(lib.yolo_pack_weights(w.data_ptr(), wp.data_ptr(), cout, cin, k, code, st))
