@@ -1926,10 +1926,18 @@ static size_t cls_frag_elems(int cin, int cout, int cls) {       // N = cin (dx 
     return (size_t)(round_up(cin, 128) / 32) * (cout / 32) * nt * 1024;
 }
 
+// all four parity classes of one layer in ONE launch (they were four ~6 us launches per layer and step): the classes'
+// fragment streams lie back to back in `wf`; `end[cls]` = end of class cls in that concatenation
+struct S2ClsEnds { long long end[4]; };
 template <typename T>
-__global__ void pack_dgrad_s2_cls_h16(const float* __restrict__ w, unsigned short* __restrict__ wf, int cout, int cin, int ph, int pw,
-                                      int NT, int KT, long long total) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+__global__ void pack_dgrad_s2_cls_h16(const float* __restrict__ w, unsigned short* __restrict__ wf, int cout, int cin, S2ClsEnds ends) {
+    const long long total = ends.end[3];
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int cls = g < ends.end[0] ? 0 : (g < ends.end[1] ? 1 : (g < ends.end[2] ? 2 : 3));
+        const long long i = g - (cls ? ends.end[cls - 1] : 0);
+        const int ph = cls >> 1, pw = cls & 1;
+        const int NT = (ph + 1) * (pw + 1);                       // taps of the class: 1, 2, 2, 4
+        const int KT = (cout / 32) * NT;
         const int e = (int)(i & 7);
         const int lane = (int)((i >> 3) & 63);
         const int s = (int)((i >> 9) & 1);
@@ -1942,7 +1950,7 @@ __global__ void pack_dgrad_s2_cls_h16(const float* __restrict__ w, unsigned shor
         const int kh = ph + 1 - 2 * dh, kw = pw + 1 - 2 * dw;
         const int co = chunk * 32 + s * 16 + 8 * (lane >> 5) + e;
         const float v = (ci < cin && co < cout) ? w[((size_t)co * cin + ci) * 9 + kh * 3 + kw] : 0.f;
-        wf[i] = HTraits<T>::from_f32(v);
+        wf[g] = HTraits<T>::from_f32(v);
     }
 }
 
@@ -1953,22 +1961,19 @@ size_t h16_dgrad_s2_elems(int cout, int cin) {
 }
 
 int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtype, hipStream_t s) {
-    unsigned short* dst = (unsigned short*)wf;
+    S2ClsEnds ends;
+    long long acc = 0;
     for (int cls = 0; cls < 4; ++cls) {
-        const int ph = cls >> 1, pw = cls & 1;
-        const int NT = mask_count(cls_mask(ph, pw));
-        const long long total = (long long)cls_frag_elems(cin, cout, cls);
-        const int KT = (cout / 32) * NT;
-        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        if (dtype == YOLO_BF16)
-            hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<__bf16>, dim3(grid), dim3(256), 0, s, w_oihw, dst, cout, cin, ph, pw, NT, KT, total);
-        else
-            hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, dst, cout, cin, ph, pw, NT, KT, total);
-        const int rc = check_launch("pack_dgrad_s2_cls_h16");
-        if (rc) return rc;
-        dst += total;
+        if (mask_count(cls_mask(cls >> 1, cls & 1)) != ((cls >> 1) + 1) * ((cls & 1) + 1)) return fail(YOLO_ERR_ARG, "dgrad_s2: class taps");
+        acc += (long long)cls_frag_elems(cin, cout, cls);
+        ends.end[cls] = acc;
     }
-    return YOLO_OK;
+    const int grid = (int)((acc + 255) / 256 < 8192 ? (acc + 255) / 256 : 8192);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<__bf16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ends);
+    else
+        hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ends);
+    return check_launch("pack_dgrad_s2_cls_h16");
 }
 
 static void fill_magics(ConvHArgs& a) {
