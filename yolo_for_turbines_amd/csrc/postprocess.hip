@@ -627,11 +627,16 @@ __global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict
     if ((q & 63) == 63 || q == nv - 1) blk_hi[(size_t)b * W + (q >> 6)] = cls;
 }
 
+// The words of the diagonal and of the SCAN_NEAR column blocks after it are ALSO stored as near[b][rb][d][lane] (d = cb - rb):
+// the scan reads exactly those for all 64 rows of a block at once, and in the mask itself they are 64 separate cache lines
+// (one per row, W words apart) - an uncoalesced, HBM-latency load on the scan's serial chain; here they are 512 contiguous bytes.
+constexpr int SCAN_NEAR = 3;
+
 // grid (S = 4, W, B), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
 __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
                                                              const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
                                                              int W, float thr, unsigned long long* __restrict__ mask,
-                                                             unsigned long long* __restrict__ row_any) {
+                                                             unsigned long long* __restrict__ row_any, unsigned long long* __restrict__ near) {
     const int rb = blockIdx.y, b = blockIdx.z;
     const int nv = nvalid[b];
     if (rb * 64 >= nv) return;
@@ -651,6 +656,7 @@ __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restr
         const int lim = nv - cb * 64 < 64 ? nv - cb * 64 : 64;
         const unsigned long long word = suppression_word(me, active, i, cols, lim, cb * 64, thr, sb + cb * 64);
         if (active) mask[((size_t)b * n + i) * W + cb] = word;
+        if (active && cb - rb <= SCAN_NEAR) near[(((size_t)b * W + rb) * (SCAN_NEAR + 1) + (cb - rb)) * 64 + threadIdx.x] = word;
         const unsigned long long bal = __ballot(active && word != 0ull);
         if (cb > rb && threadIdx.x == 0 && bal) atomicOr(&row_any[(size_t)b * W + rb], bal);
     }
@@ -822,13 +828,215 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
 // A 64-row block that straddles a cut is visited by both neighbours, each with its own row mask. Kept rows are reported
 // as bits of keptw (atomicOr: straddling blocks) and placed in output order by nms_place_kernel.
 constexpr int SCAN_MLP = 8;
+
+// ---- few classes: a TEAM of waves per class range ------------------------------------------------------------------------
+// With 2 classes only 2 of an image's 16 waves had a range, and each spent its time waiting for the kept rows' mask words
+// (5-6 dependent rounds of loads per 64-row block, ~2.2 us per block, 78 blocks in a chain). When at most half the waves
+// have a range, every range gets G = K / ranges waves: a leader that walks the serial chain and G - 1 helpers that do the
+// far pushes, talking through LDS (all waves of a workgroup are resident, so a spin on an LDS word cannot deadlock; LDS
+// operations of one wave execute in order, so "data, then counter" needs no wait in between):
+//   * columns rb + 1 .. rb + SCAN_NEAR of row block rb are the leader's: it loads the 64 rows' words of those columns
+//     UNCONDITIONALLY two iterations ahead (no dependence on which rows are kept) and, once the kept word of block rb - d is
+//     known, ORs the kept rows' words together across the wave (DPP) - no memory latency on the chain;
+//   * columns beyond belong to the helpers, in S sets that take the row blocks in turn (block k -> set k % S): the leader
+//     publishes kept & row_any of block rb in a ring, the helpers of that set split its rows (t % P), OR the words into the
+//     team's removed[] (ds_or) and report the block done. The leader only needs block rb - SCAN_NEAR - 1 finished before it
+//     resolves block rb, and it reads the progress counters and removed[rb + 1] one iteration early (counters first: if they
+//     pass, the word read after them is complete), so no LDS round trip sits on the chain either.
+constexpr int SCAN_RING = 8;                // > SCAN_NEAR + 1: the leader is never further ahead of a helper than that
+constexpr int SCAN_HELP_MLP = 16;           // rows in flight per helper (x 2 column slices)
+
+__device__ __forceinline__ unsigned wave_or32(unsigned v) {       // OR over the 64 lanes (all active), result wave-uniform
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);     // row_half_mirror
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);     // row_mirror: every lane holds its row's OR
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+
+// one member of a team; returns the number of kept rows (leader) or 0 (helpers). `removed` is the team's word array, `ctrl`
+// its control block (both zeroed): ring[SCAN_RING] u64, then int pub, pad, int prog[H]. `single`: the range is one class
+// bucket, so every word the team touches was written by the mask kernel. Byte offsets into the image's mask are 32-bit.
+__device__ __forceinline__ int scan_team(const unsigned long long* __restrict__ mk, const unsigned long long* __restrict__ any,
+                                         const int* lo, const int* hi, int W, int s0, int s1, bool single, unsigned long long* removed,
+                                         unsigned long long* ctrl, int member, int H, int lane, unsigned long long* __restrict__ keptw_b,
+                                         const unsigned long long* __restrict__ near_b) {
+    // relaxed workgroup-scope atomics, not volatile: the address-space inference leaves volatile accesses as flat loads
+    unsigned long long* ring = ctrl;
+    int* pub = (int*)(ctrl + SCAN_RING);
+    int* prog = pub + 2;
+    auto ld = [](const int* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto st = [](int* q, int v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const int rb0 = s0 >> 6, rb1 = (s1 - 1) >> 6;
+    const unsigned W8 = (unsigned)W * 8u;
+    const char* mkb = reinterpret_cast<const char*>(mk);
+    const int S = H >= 6 ? 3 : (H >= 2 ? 2 : 1);
+    auto rows_of = [&](int rb) -> unsigned long long {   // rows of block rb inside [s0, s1)
+        const int a = s0 - rb * 64 > 0 ? s0 - rb * 64 : 0, z = s1 - rb * 64 < 64 ? s1 - rb * 64 : 64;
+        const unsigned long long upto = z == 64 ? ~0ull : ((1ull << z) - 1ull);
+        return upto & ~((1ull << a) - 1ull);
+    };
+    if (member == 0) {
+        // branch-free prefetch: the address is clamped into the range's rows and column blocks and the word is masked when it
+        // is used (a load under a branch makes the compiler wait for vmcnt(0), i.e. for the prefetches just issued, too)
+        auto word_of = [&](int rr, int c) -> unsigned long long {       // row rr * 64 + lane, column block c = rr + d, d <= SCAN_NEAR
+            const int rs = rr < rb0 ? rb0 : (rr > rb1 ? rb1 : rr);      // any valid address; what is out of range is never used
+            return near_b[(size_t)((rs * (SCAN_NEAR + 1) + (c - rr)) * 64 + lane)];
+        };
+        auto near_ok = [&](int rr, int c) -> bool { return single || lo[c] <= hi[rr > rb0 ? rr : rb0]; };   // else never written
+        // two register sets, used alternately (the loop is unrolled by two): a set is consumed and then refilled for the block
+        // two iterations ahead, so no in-flight load result is ever copied (a rotation n0 = n1 would wait for vmcnt(0))
+        // row_any through the VECTOR memory path: a scalar load shares lgkmcnt with LDS and returns out of order, so every wait for
+        // an LDS word would also wait for the s_load just issued - a global-memory latency on the chain, every iteration
+        int vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+        struct Pre { unsigned long long d, a, n[SCAN_NEAR]; };
+        auto fill = [&](Pre& p, int c) {
+            p.d = word_of(c, c);
+            p.a = any[(c < rb1 ? c : rb1) + vzero];
+#pragma unroll
+            for (int q = 0; q < SCAN_NEAR; ++q) p.n[q] = word_of(c - (q + 1), c);
+        };
+        Pre X, Y;
+        fill(X, rb0);
+        fill(Y, rb0 + 1);
+        unsigned long long kp[SCAN_NEAR];              // kept words of blocks rb - 1, rb - 2, ... (0 before the range)
+#pragma unroll
+        for (int q = 0; q < SCAN_NEAR; ++q) kp[q] = 0ull;
+        int count = 0;
+        const int lane_set = lane % S;
+        int needv = 0, phase = 0;                       // per lane (= helper): blocks that helper must have finished
+        int pg = 0;                                     // its progress counter, read one iteration early ...
+        unsigned long long rv = removed[rb0];           // ... followed by the removed word of the block
+        auto iter = [&](int rb, Pre& p) {
+            const int k = rb - rb0;
+            const unsigned long long rowmask = rows_of(rb);
+            const unsigned long long d = ((rowmask >> lane) & 1ull) ? p.d : 0ull, any_rb = uniform64(p.a);
+            unsigned long long v = 0ull;
+#pragma unroll
+            for (int q = 0; q < SCAN_NEAR; ++q) v |= (near_ok(rb - (q + 1), rb) && ((kp[q] >> lane) & 1ull)) ? p.n[q] : 0ull;
+            const unsigned long long near_rem = ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+            fill(p, rb + 2);
+            const int kk = k - SCAN_NEAR - 1;           // the block whose far pushes become necessary now (its set: kk % S)
+            if (kk >= 0) {
+                if (lane_set == phase) needv = kk + 1;
+                phase = phase + 1 == S ? 0 : phase + 1;
+            }
+            if (__ballot(lane < H && pg < needv) != 0ull) {          // a helper is behind: wait, then read the word again
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    pg = lane < H ? ld(prog + lane) : 0x7fffffff;
+                } while (__ballot(lane < H && pg < needv) != 0ull);
+                asm volatile("" ::: "memory");
+                rv = removed[rb];
+            }
+            unsigned long long rem = uniform64(rv) | near_rem;
+            {                                                        // next block's counters, then its word (in this order)
+                pg = lane < H ? ld(prog + lane) : 0x7fffffff;
+                asm volatile("" ::: "memory");
+                rv = removed[rb + 1 <= rb1 ? rb + 1 : rb1];
+            }
+            unsigned long long cand = __ballot(d != 0ull);
+            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+            while (cand) {                              // only rows with a diagonal bit can change the outcome
+                const int t = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (!((rem >> t) & 1ull)) {
+                    const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                    const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                    rem |= ((unsigned long long)wh << 32) | wl;
+                }
+            }
+            const unsigned long long kept = rowmask & ~rem;
+            const unsigned long long work = kept & any_rb;
+            if (lane == 0) {
+                __hip_atomic_store(ring + (k & (SCAN_RING - 1)), work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");          // the ring entry before the counter (in-order LDS: no wait needed)
+                st(pub, k + 1);
+                if (kept) atomicOr(&keptw_b[rb], kept);
+            }
+            count += __popcll(kept);
+#pragma unroll
+            for (int q = SCAN_NEAR - 1; q > 0; --q) kp[q] = kp[q - 1];
+            kp[0] = kept;
+        };
+        for (int rb = rb0; rb <= rb1; rb += 2) {
+            iter(rb, X);
+            if (rb + 1 <= rb1) iter(rb + 1, Y);
+        }
+        return count;
+    }
+    const int h = member - 1;
+    const int set = h % S, part = h / S, P = (H - set + S - 1) / S;      // this helper: part `part` of the P helpers of its set
+    const unsigned long long sel = __ballot(lane % P == part);
+    for (int k = set; k <= rb1 - rb0; k += S) {
+        const int rb = rb0 + k;
+        while (__builtin_amdgcn_readfirstlane(ld(pub)) <= k) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+#ifdef SCAN_DBG_NOHELP
+        const unsigned long long work = 0ull & sel;
+#else
+        const unsigned long long work = uniform64(__hip_atomic_load(ring + (k & (SCAN_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & sel;
+#endif
+        if (work) {
+            const int hi_r = hi[rb];
+            const char* blkp = mkb + (size_t)((unsigned)(rb * 64) * W8);
+            for (int cb = rb + SCAN_NEAR + 1; cb <= rb1; cb += 128) {           // two column slices (lane, lane + 64) per pass
+                const int c0 = cb + lane, c1 = c0 + 64;
+                const int cc0 = c0 < rb1 ? c0 : rb1, cc1 = c1 < rb1 ? c1 : rb1;   // clamped: unconditional loads, masked below
+                const bool ok0 = c0 <= rb1 && (single || lo[cc0] <= hi_r);       // else never written: classes above this row block's
+                const bool ok1 = c1 <= rb1 && (single || lo[cc1] <= hi_r);
+                const unsigned o0 = (unsigned)cc0 * 8u, o1 = (unsigned)cc1 * 8u;
+                unsigned long long acc0 = 0ull, acc1 = 0ull, wk = work;
+                int tl = 0;
+                if (__ballot(ok1) != 0ull) {
+                    while (wk) {                        // SCAN_HELP_MLP rows' words in flight (a spent slot repeats the last row)
+                        unsigned long long w0[SCAN_HELP_MLP], w1[SCAN_HELP_MLP];
+#pragma unroll
+                        for (int u = 0; u < SCAN_HELP_MLP; ++u) {
+                            if (wk) { tl = __builtin_ctzll(wk); wk &= wk - 1ull; }
+                            const char* rowp = blkp + (size_t)((unsigned)tl * W8);
+                            w0[u] = *reinterpret_cast<const unsigned long long*>(rowp + o0);
+                            w1[u] = *reinterpret_cast<const unsigned long long*>(rowp + o1);
+                        }
+#pragma unroll
+                        for (int u = 0; u < SCAN_HELP_MLP; ++u) { acc0 |= w0[u]; acc1 |= w1[u]; }
+                    }
+                } else {
+                    while (wk) {
+                        unsigned long long w0[SCAN_HELP_MLP];
+#pragma unroll
+                        for (int u = 0; u < SCAN_HELP_MLP; ++u) {
+                            if (wk) { tl = __builtin_ctzll(wk); wk &= wk - 1ull; }
+                            w0[u] = *reinterpret_cast<const unsigned long long*>(blkp + (size_t)((unsigned)tl * W8) + o0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < SCAN_HELP_MLP; ++u) acc0 |= w0[u];
+                    }
+                }
+                if (ok0 && acc0) atomicOr(&removed[c0], acc0);       // several helpers share a word
+                if (ok1 && acc1) atomicOr(&removed[c1], acc1);
+            }
+        }
+        asm volatile("" ::: "memory");                  // the ORs before the progress counter (in-order LDS)
+        if (lane == 0) st(prog + h, k + 1);
+    }
+    return 0;
+}
+
 __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned long long* __restrict__ mask,
                                                                const unsigned long long* __restrict__ sorted2,
                                                                const int* __restrict__ nvalid, const unsigned long long* __restrict__ row_any,
                                                                const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n, int W,
-                                                               unsigned long long* __restrict__ keptw, int* __restrict__ keep_count) {
+                                                               unsigned long long* __restrict__ keptw, int* __restrict__ keep_count,
+                                                               const unsigned long long* __restrict__ near) {
     extern __shared__ unsigned long long lds[];         // [K][W] removed words per wave, then lo[W], hi[W] (int), the count, cuts
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, K = blockDim.x >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, K = blockDim.x >> 6;
     const int nv = nvalid[b];
     const int nblk = (nv + 63) / 64;
     unsigned long long* removed = lds + (size_t)wave * W;
@@ -839,42 +1047,70 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
     for (int c = tid; c < nblk; c += blockDim.x) { lo[c] = blk_lo[(size_t)b * W + c]; hi[c] = blk_hi[(size_t)b * W + c]; }
     if (tid == 0) *total = 0;
     __syncthreads();
-    // range of this wave: cuts at the first class boundary at or after k nv / K (upper bound of the bucket just before it)
+    // range of this wave: cuts at the first class boundary at or after k nv / K (upper bound of the bucket just before it).
+    // Wave k - 1 finds cut k: the first block that STARTS above the target's bucket from the block classes in LDS, then the
+    // exact row with one 64-key load of the block before it (a per-thread binary search over the keys was ~14 dependent
+    // global loads, 10+ us before any wave could start).
     const unsigned long long* keys = sorted2 + (size_t)b * n;
-    auto cut = [&](int k) -> int {
-        if (k <= 0) return 0;
-        if (k >= K) return nv;
-        const int target = (int)((long long)nv * k / K);
-        if (target <= 0) return 0;
-        const unsigned bucket = (unsigned)((keys[target - 1] >> 40) & 0xfffull);
-        int a = target, z = nv;                         // first q in [target, nv) with bucket(q) > bucket; buckets ascend
-        while (a < z) {
-            const int m = (a + z) >> 1;
-            if ((unsigned)((keys[m] >> 40) & 0xfffull) > bucket) z = m; else a = m + 1;
+    int* cuts = total + 1;                              // [K + 1]
+    if (tid == 0) { cuts[0] = 0; cuts[K] = nv; }
+    if (wave + 1 < K) {
+        const int target = (int)((long long)nv * (wave + 1) / K);
+        int res = 0;
+        if (target > 0) {
+            const int bucket = (int)(unsigned)((keys[target - 1] >> 40) & 0xfffull);      // uniform
+            const int tb = target >> 6;
+            int c = nblk;                               // first block after tb whose first row is above the bucket
+            for (int c0 = tb + 1; c0 < nblk; c0 += 64) {
+                const unsigned long long above = __ballot(c0 + lane < nblk && lo[c0 + lane] > bucket);
+                if (above) { c = c0 + __builtin_ctzll(above); break; }
+            }
+            const int q = (c - 1) * 64 + lane;          // the boundary is inside block c - 1 or at the start of block c
+            const bool in = q >= target && q < nv;
+            const unsigned long long key = keys[in ? q : target - 1];
+            const unsigned long long above = __ballot(in && (int)(unsigned)((key >> 40) & 0xfffull) > bucket);
+            res = above ? (c - 1) * 64 + __builtin_ctzll(above) : (c * 64 < nv ? c * 64 : nv);
         }
-        return a;
-    };
-    int* cuts = total + 1;                              // [K + 1], one binary search each, in parallel
-    if (tid <= K) cuts[tid] = cut(tid);
+        if (lane == 0) cuts[wave + 1] = res;
+    }
     __syncthreads();
-    const int s0 = cuts[wave], s1 = cuts[wave + 1];
+    int R = 0;                                          // ranges that hold rows
+    for (int k = 0; k < K; ++k) R += cuts[k] < cuts[k + 1] ? 1 : 0;
+    const int G = (R > 0 && 2 * R <= K && (unsigned long long)n * W * 8ull < (1ull << 32)) ? K / R : 1;   // teams use 32-bit byte offsets
+    const unsigned long long* mk = mask + (size_t)b * n * W;
+    const unsigned long long* any = row_any + (size_t)b * W;
+    int s0 = 0, s1 = 0;
     int count = 0;
+    if (G >= 2) {                                       // few classes: teams of G waves (see scan_team)
+        const int team = wave / G, member = wave - team * G;
+        if (team < R) {
+            int idx = -1;
+            for (int k = 0; k < K; ++k)
+                if (cuts[k] < cuts[k + 1] && ++idx == team) { s0 = cuts[k]; s1 = cuts[k + 1]; }
+            unsigned long long* team_removed = lds + (size_t)(team * G) * W;       // the leader's array; the first helper's holds the control block
+            const bool single = ((keys[s0] >> 40) & 0xfffull) == ((keys[s1 - 1] >> 40) & 0xfffull);
+            count = scan_team(mk, any, lo, hi, W, s0, s1, single, team_removed, team_removed + W, member, G - 1, lane, keptw + (size_t)b * W,
+                              near + (size_t)b * W * (SCAN_NEAR + 1) * 64);
+        }
+        s0 = s1 = 0;
+    } else {
+        s0 = cuts[wave]; s1 = cuts[wave + 1];
+    }
     if (s0 < s1) {
-        const unsigned long long* mk = mask + (size_t)b * n * W;
-        const unsigned long long* any = row_any + (size_t)b * W;
         const int rb0 = s0 >> 6, rb1 = (s1 - 1) >> 6;
         auto rows_of = [&](int rb) -> unsigned long long {   // rows of block rb inside [s0, s1)
             const int a = s0 - rb * 64 > 0 ? s0 - rb * 64 : 0, z = s1 - rb * 64 < 64 ? s1 - rb * 64 : 64;
             const unsigned long long upto = z == 64 ? ~0ull : ((1ull << z) - 1ull);
             return upto & ~((1ull << a) - 1ull);
         };
-        unsigned long long d_next = ((rows_of(rb0) >> lane) & 1ull) ? mk[(size_t)(rb0 * 64 + lane) * W + rb0] : 0ull;
+        const unsigned long long* diag = near + (size_t)b * W * (SCAN_NEAR + 1) * 64 + lane;      // block rb's diagonal words: diag[rb * (NEAR + 1) * 64]
+        unsigned long long d_next = ((rows_of(rb0) >> lane) & 1ull) ? diag[(size_t)rb0 * (SCAN_NEAR + 1) * 64] : 0ull;
         unsigned long long any_next = any[rb0];
         for (int rb = rb0; rb <= rb1; ++rb) {
             const unsigned long long rowmask = rows_of(rb);
             const unsigned long long d = d_next, any_rb = any_next;
             if (rb < rb1) {
-                d_next = ((rows_of(rb + 1) >> lane) & 1ull) ? mk[(size_t)((rb + 1) * 64 + lane) * W + rb + 1] : 0ull;
+                d_next = ((rows_of(rb + 1) >> lane) & 1ull) ? diag[(size_t)(rb + 1) * (SCAN_NEAR + 1) * 64] : 0ull;
                 any_next = any[rb + 1];
             }
             const unsigned long long rem_v = removed[rb];   // wave-uniform: keep the serial chain on the scalar unit
@@ -934,7 +1170,7 @@ static const bool g_nms_rocprim = getenv("YOLO_NMS_ROCPRIM") != nullptr;       /
 struct NmsWs { int* nvalid; unsigned long long* row_any; int* order; SBox* sbox; unsigned long long* mask; size_t zero_bytes; size_t total;
                unsigned long long* keys_in; unsigned long long* keys_out; void* sort_tmp; size_t sort_tmp_bytes;
                int* grank; int* blk_lo; int* blk_hi; unsigned long long* keptw; int* chunk_valid; unsigned long long* chunked;
-               unsigned long long* sorted2; };
+               unsigned long long* sorted2; unsigned long long* near; };
 
 static size_t sort_tmp_bytes(int b, int n) {
     size_t bytes = 0;
@@ -969,6 +1205,7 @@ static NmsWs carve(void* base, int b, int n) {
     const bool own_sort = n <= SC * SC_MAXCH;
     w.chunked = (unsigned long long*)take(own_sort ? sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * ceil_div(n > 0 ? n : 1, SC) * SC : 8);
     w.sorted2 = (unsigned long long*)take(own_sort ? sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * (n > 0 ? n : 1) : 8);
+    w.near = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W * (SCAN_NEAR + 1) * 64);
     w.total = off;
     return w;
 }
@@ -1102,12 +1339,12 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         // block costs launch time (80 classes: 0.212 / 0.221 / 0.250 / 0.305 ms for 3 / 4 / 8 / 16), with 2 classes more
         // blocks help a little (1.16 / 1.12 / 1.05 / 1.02 ms)
         hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(W < 4 ? W : 4, W, b), dim3(64), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
-                           W, (float)iou_threshold, w.mask, w.row_any);
+                           W, (float)iou_threshold, w.mask, w.row_any, w.near);
         rc = check_launch("nms_mask_sorted");
         if (rc) return rc;
         const size_t lds = (size_t)K * W * 8 + fixed;
         hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(b), dim3(64 * K), lds, st, w.mask, w.keys_out, w.nvalid, w.row_any, w.blk_lo,
-                           w.blk_hi, n, W, w.keptw, keep_count);
+                           w.blk_hi, n, W, w.keptw, keep_count, w.near);
         rc = check_launch("nms_scan_classes");
         if (rc) return rc;
         hipLaunchKernelGGL(nms_place_kernel, gn, dim3(256), 0, st, w.keptw, w.order, w.grank, w.nvalid, n, W, slot);
