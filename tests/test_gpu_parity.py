@@ -290,6 +290,44 @@ def test_nms_class_sorted_path_awkward_classes(yt):
     np.testing.assert_array_equal(keep[:int(count)].cpu().numpy(), opp.nms_indices_c(batch[0], 0.0, -1.0, "corner"))
 
 
+@pytest.mark.parametrize("thr", [0.05, 0.3, 0.45, 0.5, 0.75, 0.95])
+@pytest.mark.parametrize("scale", [1.0, 416.0, 1.0e4])
+def test_nms_candidate_bounds_pairs_at_the_threshold(yt, thr, scale):
+    """The mask kernel's first pass only admits pairs whose overlap is wide and high enough to reach the threshold at all
+    (per-row bounds derived from thr); the exact pass decides the rest. Pairs built to sit within 1e-3 .. 1e-7 of the threshold
+    - shifted copies, shifted along both axes, contained boxes, extreme aspect ratios, boxes a few ulps wide at the given
+    coordinate scale - in two classes (class-uniform 64-blocks, the fast path) and n >= 2048 (the class-sorted path):
+    kept indices exactly the C oracle's."""
+    rng = np.random.Generator(np.random.PCG64(int(thr * 1000) + int(scale)))
+    n_pairs = 2048
+    w = scale * 10.0 ** rng.uniform(-4.0, -0.5, n_pairs)
+    h = w * 10.0 ** rng.uniform(-1.5, 1.5, n_pairs)
+    cx, cy = scale * rng.random(n_pairs), scale * rng.random(n_pairs)
+    eps = rng.choice([1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 0.0], n_pairs) * rng.choice([-1.0, 1.0], n_pairs)
+    t = np.clip(thr * (1.0 + eps), 1e-3, 0.999)
+    kind = rng.integers(0, 4, n_pairs)
+    px, py, pw, ph = cx.copy(), cy.copy(), w.copy(), h.copy()
+    d = (1.0 - t) / (1.0 + t)                        # equal boxes shifted by d * extent along one axis: IoU = t
+    px = np.where(kind == 0, cx + d * w, px)
+    py = np.where(kind == 1, cy + d * h, py)
+    s = 1.0 - np.sqrt(2.0 * t / (1.0 + t))          # shifted by s * extent along both: overlap (1 - s)^2 = 2 t / (1 + t)
+    px = np.where(kind == 2, cx + s * w, px)
+    py = np.where(kind == 2, cy - s * h, py)
+    pw = np.where(kind == 3, w * t, pw)              # contained: IoU = area ratio = t
+    cls = rng.integers(0, 2, n_pairs).astype(np.float64)
+    score_a = 0.6 + 0.4 * rng.random(n_pairs)
+    score_b = score_a - 0.05 * rng.random(n_pairs) - 1e-3
+    a = np.stack([cx, cy, w, h, score_a, cls], 1)
+    b = np.stack([px, py, pw, ph, score_b, cls], 1)
+    boxes = np.concatenate([a, b]).astype(F32)
+    boxes = boxes[rng.permutation(len(boxes))]
+    keep, count = yt.nms_indices(torch.from_numpy(boxes).cuda(), thr, 0.5, "center")
+    want = opp.nms_indices_c(boxes, thr, 0.5, "center")
+    assert int(count) == len(want)
+    np.testing.assert_array_equal(keep[:int(count)].cpu().numpy(), want)
+    assert 32 < 2 * n_pairs - len(want) < 2 * n_pairs - 32             # both outcomes occur (at scale 1 the + 1e-6 of the denominator rescues tiny boxes)
+
+
 @pytest.mark.parametrize("n,nc", [(2048, 80), (4096, 3), (4097, 80), (12288, 20), (22743, 80), (32768, 80), (33000, 80)])
 def test_nms_ordering_kernels_chunk_counts(yt, n, nc):
     """The hand-written ordering (2,048-key chunks sorted in LDS + rank merge) for 1 .. 16 chunks per image, chunk

@@ -260,9 +260,33 @@ __device__ __forceinline__ bool tame_box(const SBox& q) {
     return fabsf(q.x1) < lim && fabsf(q.y1) < lim && fabsf(q.x2) < lim && fabsf(q.y2) < lim && fabsf(q.area) < lim;
 }
 
+// Per-row bounds of the fast path's candidate test (below): the column must reach x2 >= lo_x, x1 <= hi_x, y2 >= lo_y, y1 <= hi_y.
+// The loose form is "the boxes overlap". The tight form uses what !(iou < thr) implies for thr > 0 with positive areas: from
+// iou = fl(inter / den) >= thr and den = fl(fl(fl(a1 + a2) - inter) + 1e-6) follows inter >= 0.99 (thr / (1 + thr)) a1 (every
+// rounding is a factor 1 +- 2^-24; a2 >= 0), and inter = fl(iw ih) with ih <= fl(y2 - y1) of the row itself, so the width of the
+// intersection must be at least T = 0.98 (thr / (1 + thr)) a1 / fl(y2 - y1) - and its height U likewise. For equal-sized boxes at
+// thr = 0.45 that halves the candidates the exact pass has to divide for, and it costs nothing per pair: the four compares
+// stay, only their per-row constants move. The bounds are rounded outwards by a few ulps; a pair they admit wrongly is still
+// decided by the exact pass, so the result cannot change - a pair they reject is one the exact formula cannot suppress.
+struct RowBounds { float lo_x, hi_x, lo_y, hi_y; };
+__device__ __forceinline__ RowBounds row_bounds(const SBox& me, float thr) {
+    float T = 0.f, U = 0.f;
+    const float ew = me.x2 - me.x1, eh = me.y2 - me.y1;
+    if (thr > 1e-6f && thr < 1e3f && me.area > 1e-30f && ew > 1e-30f && eh > 1e-30f) {
+        const float kf = 0.98f * (thr / (1.0f + thr)) * me.area;
+        T = kf * __builtin_amdgcn_rcpf(eh);
+        U = kf * __builtin_amdgcn_rcpf(ew);
+    }
+    RowBounds r;
+    r.lo_x = me.x1 + T; r.hi_x = me.x2 - T; r.lo_y = me.y1 + U; r.hi_y = me.y2 - U;
+    r.lo_x -= fabsf(r.lo_x) * 0x1p-21f; r.hi_x += fabsf(r.hi_x) * 0x1p-21f;       // outwards: the sums above were rounded
+    r.lo_y -= fabsf(r.lo_y) * 0x1p-21f; r.hi_y += fabsf(r.hi_y) * 0x1p-21f;
+    return r;
+}
+
 template <bool TAME>
 __device__ __forceinline__ unsigned long long suppression_word(const SBox& me, bool active, int i, const SBox* cols, int lim, int col0,
-                                                              float thr, const SBox* __restrict__ gcols) {
+                                                              float thr, const SBox* __restrict__ gcols, const RowBounds& rbnd) {
     unsigned long long word = 0;
     if (TAME) {
         // Two passes. (1) all 64 columns, ~10 instructions per pair: CANDIDATE = same class and the boxes overlap in x and in y
@@ -324,24 +348,24 @@ __device__ __forceinline__ unsigned long long suppression_word(const SBox& me, b
 #define NMS_COL4(q) \
                     { unsigned long long sv; \
                       asm volatile("s_mov_b64 %[sv], exec\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[a3], %[mx2]\n\tv_cmpx_gt_f32_e32 vcc, %[c3], %[mx1]\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[b3], %[my2]\n\tv_cmpx_gt_f32_e32 vcc, %[d3], %[my1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[a3], %[mx2]\n\tv_cmpx_ge_f32_e32 vcc, %[c3], %[mx1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[b3], %[my2]\n\tv_cmpx_ge_f32_e32 vcc, %[d3], %[my1]\n\t" \
                                    "s_mov_b64 exec, %[sv]\n\tv_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[a2], %[mx2]\n\tv_cmpx_gt_f32_e32 vcc, %[c2], %[mx1]\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[b2], %[my2]\n\tv_cmpx_gt_f32_e32 vcc, %[d2], %[my1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[a2], %[mx2]\n\tv_cmpx_ge_f32_e32 vcc, %[c2], %[mx1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[b2], %[my2]\n\tv_cmpx_ge_f32_e32 vcc, %[d2], %[my1]\n\t" \
                                    "s_mov_b64 exec, %[sv]\n\tv_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[a1], %[mx2]\n\tv_cmpx_gt_f32_e32 vcc, %[c1], %[mx1]\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[b1], %[my2]\n\tv_cmpx_gt_f32_e32 vcc, %[d1], %[my1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[a1], %[mx2]\n\tv_cmpx_ge_f32_e32 vcc, %[c1], %[mx1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[b1], %[my2]\n\tv_cmpx_ge_f32_e32 vcc, %[d1], %[my1]\n\t" \
                                    "s_mov_b64 exec, %[sv]\n\tv_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[a0], %[mx2]\n\tv_cmpx_gt_f32_e32 vcc, %[c0], %[mx1]\n\t" \
-                                   "v_cmpx_lt_f32_e32 vcc, %[b0], %[my2]\n\tv_cmpx_gt_f32_e32 vcc, %[d0], %[my1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[a0], %[mx2]\n\tv_cmpx_ge_f32_e32 vcc, %[c0], %[mx1]\n\t" \
+                                   "v_cmpx_le_f32_e32 vcc, %[b0], %[my2]\n\tv_cmpx_ge_f32_e32 vcc, %[d0], %[my1]\n\t" \
                                    "s_mov_b64 exec, %[sv]\n\tv_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc" \
                                    : [w] "+v"(w), [sv] "=&s"(sv) \
                                    : [a0] "s"(c8[q][0]), [b0] "s"(c8[q][1]), [c0] "s"(c8[q][2]), [d0] "s"(c8[q][3]), \
                                      [a1] "s"(c8[q + 1][0]), [b1] "s"(c8[q + 1][1]), [c1] "s"(c8[q + 1][2]), [d1] "s"(c8[q + 1][3]), \
                                      [a2] "s"(c8[q + 2][0]), [b2] "s"(c8[q + 2][1]), [c2] "s"(c8[q + 2][2]), [d2] "s"(c8[q + 2][3]), \
                                      [a3] "s"(c8[q + 3][0]), [b3] "s"(c8[q + 3][1]), [c3] "s"(c8[q + 3][2]), [d3] "s"(c8[q + 3][3]), \
-                                     [mx1] "v"(me.x1), [my1] "v"(me.y1), [mx2] "v"(me.x2), [my2] "v"(me.y2) \
+                                     [mx1] "v"(rbnd.lo_x), [my1] "v"(rbnd.lo_y), [mx2] "v"(rbnd.hi_x), [my2] "v"(rbnd.hi_y) \
                                    : "vcc"); }
                     NMS_COL4(4)
                     NMS_COL4(0)
@@ -404,10 +428,11 @@ __device__ __forceinline__ unsigned long long suppression_word(const SBox& me, b
 }
 
 __device__ __forceinline__ unsigned long long suppression_word(const SBox& me, bool active, int i, const SBox* cols, int lim, int col0,
-                                                              float thr, const SBox* __restrict__ gcols = nullptr) {
+                                                              float thr, const SBox* __restrict__ gcols = nullptr,
+                                                              const RowBounds& rbnd = RowBounds{0.f, 0.f, 0.f, 0.f}) {
     const bool wild = (active && !tame_box(me)) || ((int)(threadIdx.x & 63) < lim && !tame_box(cols[threadIdx.x & 63]));
-    return __ballot(wild) == 0ull ? suppression_word<true>(me, active, i, cols, lim, col0, thr, gcols)
-                                  : suppression_word<false>(me, active, i, cols, lim, col0, thr, gcols);
+    return __ballot(wild) == 0ull ? suppression_word<true>(me, active, i, cols, lim, col0, thr, gcols, rbnd)
+                                  : suppression_word<false>(me, active, i, cols, lim, col0, thr, gcols, rbnd);
 }
 
 // ---- class-sorted variant (large n) ---------------------------------------------------------------------------------
@@ -632,12 +657,14 @@ __global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict
 // (one per row, W words apart) - an uncoalesced, HBM-latency load on the scan's serial chain; here they are 512 contiguous bytes.
 constexpr int SCAN_NEAR = 3;
 
-// grid (S = 4, W, B), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
+// grid (S = 4, B, W), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
 __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
                                                              const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
                                                              int W, float thr, unsigned long long* __restrict__ mask,
                                                              unsigned long long* __restrict__ row_any, unsigned long long* __restrict__ near) {
-    const int rb = blockIdx.y, b = blockIdx.z;
+    // row block slowest, image in the middle: the workgroups are dispatched in that order, and a row block's work shrinks
+    // along its class range, so with the image slowest the last images' longest workgroups started late and ran alone at the end
+    const int rb = blockIdx.z, b = blockIdx.y;
     const int nv = nvalid[b];
     if (rb * 64 >= nv) return;
     const int nblk = (nv + 63) / 64;
@@ -647,6 +674,7 @@ __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restr
     const bool active = i < nv;
     const SBox me = sb[active ? i : nv - 1];
     const int hi_r = blk_hi[(size_t)b * W + rb];
+    const RowBounds rbnd = row_bounds(me, thr);
     for (int cb = rb + blockIdx.x; cb < nblk; cb += gridDim.x) {
         if (blk_lo[(size_t)b * W + cb] > hi_r) break;    // classes ascend: no later block can match either
         const int j = cb * 64 + threadIdx.x;
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restr
         if (j < nv) cols[threadIdx.x] = sb[j];
         __syncthreads();
         const int lim = nv - cb * 64 < 64 ? nv - cb * 64 : 64;
-        const unsigned long long word = suppression_word(me, active, i, cols, lim, cb * 64, thr, sb + cb * 64);
+        const unsigned long long word = suppression_word(me, active, i, cols, lim, cb * 64, thr, sb + cb * 64, rbnd);
         if (active) mask[((size_t)b * n + i) * W + cb] = word;
         if (active && cb - rb <= SCAN_NEAR) near[(((size_t)b * W + rb) * (SCAN_NEAR + 1) + (cb - rb)) * 64 + threadIdx.x] = word;
         const unsigned long long bal = __ballot(active && word != 0ull);
@@ -978,11 +1006,7 @@ __device__ __forceinline__ int scan_team(const unsigned long long* __restrict__ 
         const int rb = rb0 + k;
         while (__builtin_amdgcn_readfirstlane(ld(pub)) <= k) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-#ifdef SCAN_DBG_NOHELP
-        const unsigned long long work = 0ull & sel;
-#else
         const unsigned long long work = uniform64(__hip_atomic_load(ring + (k & (SCAN_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & sel;
-#endif
         if (work) {
             const int hi_r = hi[rb];
             const char* blkp = mkb + (size_t)((unsigned)(rb * 64) * W8);
@@ -1338,7 +1362,7 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         // 4 blocks per row block: with many classes only the first 2-3 column blocks are in range and every further (empty)
         // block costs launch time (80 classes: 0.212 / 0.221 / 0.250 / 0.305 ms for 3 / 4 / 8 / 16), with 2 classes more
         // blocks help a little (1.16 / 1.12 / 1.05 / 1.02 ms)
-        hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(W < 4 ? W : 4, W, b), dim3(64), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
+        hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(W < 4 ? W : 4, b, W), dim3(64), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
                            W, (float)iou_threshold, w.mask, w.row_any, w.near);
         rc = check_launch("nms_mask_sorted");
         if (rc) return rc;
