@@ -567,9 +567,11 @@ __global__ __launch_bounds__(SC_THREADS) void nms_chunksort_kernel(const float* 
         const int loc = e * SC_THREADS + tid;
         const unsigned long long key = *reinterpret_cast<const unsigned long long*>(lds + sc_addr(loc));
         out[loc] = key;
-        if (PHASE == 1 && key != ~0ull) {                 // candidates sort first: the last one reports the count (zeroed before)
+        if (PHASE == 1 && key != ~0ull) {                 // candidates sort first: the last one reports the count ...
             const unsigned long long nxt = loc + 1 < SC ? *reinterpret_cast<const unsigned long long*>(lds + sc_addr(loc + 1)) : ~0ull;
             if (nxt == ~0ull) chunk_valid[b * SC_MAXCH + c] = loc + 1;
+        } else if (PHASE == 1 && loc == 0) {
+            chunk_valid[b * SC_MAXCH + c] = 0;            // ... or the first key says there is none (no memset before the call)
         }
     }
 }
@@ -608,15 +610,15 @@ __device__ __forceinline__ int rank_in_other_chunks(const unsigned long long* __
 template <int MAXC>
 __global__ __launch_bounds__(256) void nms_merge1_kernel(const unsigned long long* __restrict__ chunked, const int* __restrict__ chunk_valid,
                                                          int nch, int n, unsigned long long* __restrict__ sorted1, int* __restrict__ nvalid,
-                                                         int* __restrict__ slot) {
+                                                         unsigned long long* __restrict__ row_any, int W) {
     const int b = blockIdx.y, c = blockIdx.x >> 3, ploc = (blockIdx.x & 7) * 256 + threadIdx.x;
     const unsigned long long* img = chunked + (size_t)b * nch * SC;
+    if (c * SC + ploc < W) row_any[(size_t)b * W + c * SC + ploc] = 0ull;       // the mask kernel ORs into it (nch SC >= n >= W)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int nv = 0;
         for (int k = 0; k < nch; ++k) nv += chunk_valid[b * SC_MAXCH + k];
         nvalid[b] = nv;
     }
-    if (c * SC + ploc < n) slot[(size_t)b * n + c * SC + ploc] = -1;     // kept boxes by global rank, -1 elsewhere (nms_place fills it)
     const unsigned long long key = img[(size_t)c * SC + ploc];
     if (key == ~0ull) return;
     const int rank = ploc + rank_in_other_chunks<MAXC>(img, nch, c, key);
@@ -690,47 +692,66 @@ __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restr
     }
 }
 
-// kept rows (bit q%64 of keptw[q/64]) go to slot[global rank]; done here, in parallel, because 64 scattered stores per
-// scan iteration had to drain before each of its barriers (the scan took 450 us that way, 2.5x the unsorted one)
-__global__ __launch_bounds__(256) void nms_place_kernel(const unsigned long long* __restrict__ keptw, const int* __restrict__ order,
-                                                        const int* __restrict__ grank, const int* __restrict__ nvalid, int n, int W,
-                                                        int* __restrict__ slot) {
-    const int b = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nvalid[b]) return;
-    if ((keptw[(size_t)b * W + (q >> 6)] >> (q & 63)) & 1ull) slot[(size_t)b * n + grank[(size_t)b * n + q]] = order[(size_t)b * n + q];
-}
-
-// kept boxes were written to slot[global rank] (-1 elsewhere): ordered compaction = the reference's output order
-__global__ __launch_bounds__(256) void nms_compact_kernel(const int* __restrict__ slot, const int* __restrict__ nvalid, int n,
-                                                          int* __restrict__ keep_idx) {
-    __shared__ int wsum[4];
+// kept boxes were written to slot[global rank] (-1 elsewhere): ordered compaction = the reference's output order.
+// One 1,024-thread workgroup per image; a pass covers CP_R rounds of 4,096 ranks (thread: 4 consecutive ranks per round) with all
+// loads issued together and TWO barriers: per-(round, wave) counts to LDS, one wave scans the CP_R x 16 counts, everybody writes.
+// (The first version did a round of 1,024 ranks per two barriers: 10 us for 10,000 ranks, one of the larger pieces at 80 classes.)
+constexpr int CP_R = 8;
+static_assert(CP_R * 16 == 128, "the prefix below scans two values per lane");
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const int* __restrict__ slot, const int* __restrict__ nvalid, int n,
+                                                           int* __restrict__ keep_idx) {
+    __shared__ int wsum[CP_R * 16], wpre[CP_R * 16 + 1];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nv = nvalid[b];
     const int* sl = slot + (size_t)b * n;
     int* out = keep_idx + (size_t)b * n;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int base = 0;
-    for (int g0 = 0; g0 < nv; g0 += 1024) {              // thread: 4 consecutive ranks per round
-        const int g = g0 + tid * 4;
-        int v[4];
-        int before = 0, wave_total = 0;
+    for (int g0 = 0; g0 < nv; g0 += CP_R * 4096) {
+        int v[CP_R][4], before[CP_R];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = g + k < nv ? sl[g + k] : -1;
-            const unsigned long long bal = __ballot(v[k] >= 0);
-            before += __popcll(bal & lt);
-            wave_total += __popcll(bal);
+        for (int r = 0; r < CP_R; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = g0 + r * 4096 + tid * 4 + k;
+                v[r][k] = g < nv ? sl[g] : -1;
+            }
+#pragma unroll
+        for (int r = 0; r < CP_R; ++r) {
+            int wave_total = 0;
+            before[r] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long bal = __ballot(v[r][k] >= 0);
+                before[r] += __popcll(bal & lt);
+                wave_total += __popcll(bal);
+            }
+            if (lane == 0) wsum[r * 16 + wave] = wave_total;
         }
         __syncthreads();
-        if (lane == 0) wsum[wave] = wave_total;
-        __syncthreads();
-        int off = base + before;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (wave == 0) {                                  // exclusive prefix of the 128 counts in (round, wave) order
+            const int a = wsum[lane], c = wsum[lane + 64];
+            int sa = a, sc = c;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (v[k] >= 0) out[off++] = v[k];
-        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ta = __shfl_up(sa, d), tc = __shfl_up(sc, d);
+                if (lane >= d) { sa += ta; sc += tc; }
+            }
+            const int tota = __shfl(sa, 63);
+            wpre[lane] = sa - a;
+            wpre[lane + 64] = tota + sc - c;
+            if (lane == 63) wpre[CP_R * 16] = tota + sc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CP_R; ++r) {
+            int off = base + wpre[r * 16 + wave] + before[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[r][k] >= 0) out[off++] = v[r][k];
+        }
+        base += wpre[CP_R * 16];
+        __syncthreads();                                  // the counts are reused by the next pass
     }
 }
 
@@ -854,7 +875,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
 // ranges of about equal length and ONE WAVE runs the greedy pass over each range, with no workgroup barrier inside the
 // loop (the per-image chain of ~160 row blocks becomes ~10 per wave at 80 classes; with 2 classes two waves work).
 // A 64-row block that straddles a cut is visited by both neighbours, each with its own row mask. Kept rows are reported
-// as bits of keptw (atomicOr: straddling blocks) and placed in output order by nms_place_kernel.
+// as bits of an LDS word array (ds_or: straddling blocks) and written to slot[global rank] at the end of the kernel.
 constexpr int SCAN_MLP = 8;
 
 // ---- few classes: a TEAM of waves per class range ------------------------------------------------------------------------
@@ -892,7 +913,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 // bucket, so every word the team touches was written by the mask kernel. Byte offsets into the image's mask are 32-bit.
 __device__ __forceinline__ int scan_team(const unsigned long long* __restrict__ mk, const unsigned long long* __restrict__ any,
                                          const int* lo, const int* hi, int W, int s0, int s1, bool single, unsigned long long* removed,
-                                         unsigned long long* ctrl, int member, int H, int lane, unsigned long long* __restrict__ keptw_b,
+                                         unsigned long long* ctrl, int member, int H, int lane, unsigned long long* keptw_b,
                                          const unsigned long long* __restrict__ near_b) {
     // relaxed workgroup-scope atomics, not volatile: the address-space inference leaves volatile accesses as flat loads
     unsigned long long* ring = ctrl;
@@ -1057,17 +1078,20 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
                                                                const unsigned long long* __restrict__ sorted2,
                                                                const int* __restrict__ nvalid, const unsigned long long* __restrict__ row_any,
                                                                const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n, int W,
-                                                               unsigned long long* __restrict__ keptw, int* __restrict__ keep_count,
-                                                               const unsigned long long* __restrict__ near) {
-    extern __shared__ unsigned long long lds[];         // [K][W] removed words per wave, then lo[W], hi[W] (int), the count, cuts
+                                                               const int* __restrict__ order, const int* __restrict__ grank,
+                                                               int* __restrict__ slot, int* __restrict__ keep_count,
+                                                               const unsigned long long* __restrict__ near,
+                                                               const unsigned long long* __restrict__ sorted1, int* __restrict__ keep_idx) {
+    extern __shared__ unsigned long long lds[];         // [K][W] removed words per wave, kept[W], then lo[W], hi[W] (int), the count, cuts
     const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, K = blockDim.x >> 6;
     const int nv = nvalid[b];
     const int nblk = (nv + 63) / 64;
     unsigned long long* removed = lds + (size_t)wave * W;
-    int* lo = (int*)(lds + (size_t)K * W);
+    unsigned long long* keptl = lds + (size_t)K * W;    // [W] kept rows, bit q % 64 of word q / 64 (ds_or: a block that straddles a cut has two writers)
+    int* lo = (int*)(lds + (size_t)(K + 1) * W);
     int* hi = lo + W;
     int* total = hi + W;
-    for (int c = tid; c < K * W; c += blockDim.x) lds[c] = 0ull;
+    for (int c = tid; c < (K + 1) * W; c += blockDim.x) lds[c] = 0ull;
     for (int c = tid; c < nblk; c += blockDim.x) { lo[c] = blk_lo[(size_t)b * W + c]; hi[c] = blk_hi[(size_t)b * W + c]; }
     if (tid == 0) *total = 0;
     __syncthreads();
@@ -1113,7 +1137,7 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
                 if (cuts[k] < cuts[k + 1] && ++idx == team) { s0 = cuts[k]; s1 = cuts[k + 1]; }
             unsigned long long* team_removed = lds + (size_t)(team * G) * W;       // the leader's array; the first helper's holds the control block
             const bool single = ((keys[s0] >> 40) & 0xfffull) == ((keys[s1 - 1] >> 40) & 0xfffull);
-            count = scan_team(mk, any, lo, hi, W, s0, s1, single, team_removed, team_removed + W, member, G - 1, lane, keptw + (size_t)b * W,
+            count = scan_team(mk, any, lo, hi, W, s0, s1, single, team_removed, team_removed + W, member, G - 1, lane, keptl,
                               near + (size_t)b * W * (SCAN_NEAR + 1) * 64);
         }
         s0 = s1 = 0;
@@ -1154,7 +1178,7 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
             }
             const unsigned long long kept = rowmask & ~rem;
             count += __popcll(kept);
-            if (lane == 0 && kept) atomicOr(&keptw[(size_t)b * W + rb], kept);
+            if (lane == 0 && kept) atomicOr(&keptl[rb], kept);
             const unsigned long long work_v = kept & any_rb;  // kept rows with a bit in some later column block
             // wave-uniform by construction; said so to the compiler, which otherwise walks the row bits with ~12 VALU
             // instructions + a 64-bit multiply per row and lane. Scalar: s_ff1 / s_andn2 per row, the row base in SGPRs and
@@ -1187,13 +1211,90 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
     if (lane == 0 && count) atomicAdd(total, count);
     __syncthreads();
     if (tid == 0) keep_count[b] = *total;
+    // Output: the kept boxes' original indices in global score order (the reference's order).
+    const int* gr = grank + (size_t)b * n;
+    if (sorted1 != nullptr) {
+        // order 1 is still around (chunk-sort path): mark the kept rows' GLOBAL RANKS in an LDS bitmap (ds_or instead of a
+        // scattered global store per kept box), prefix the words' popcounts, and let thread g emit rank g - coalesced loads of
+        // the rank's key (its low bits are the original index) and coalesced stores. Replaces the slot scatter, the slot
+        // array's -1 fill and the separate compaction launch (5 + 10 us of the 115 us at 80 classes).
+        unsigned long long* krank = lds;                 // the removed[] arrays are dead
+        int* wpre = lo;                                  // and so are the block class bounds
+        for (int c = tid; c < W; c += blockDim.x) krank[c] = 0ull;
+        __syncthreads();
+        for (int q0 = 0; q0 < nv; q0 += 4 * (int)blockDim.x) {
+            int g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {               // unconditional loads, four in flight
+                const int q = q0 + u * (int)blockDim.x + tid;
+                g[u] = gr[q < nv ? q : nv - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * (int)blockDim.x + tid;
+                if (q < nv && ((keptl[q >> 6] >> (q & 63)) & 1ull)) atomicOr(&krank[g[u] >> 6], 1ull << (g[u] & 63));
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                 // exclusive prefix of the words' popcounts: W <= 64 * 8 on this path
+            const int per = (W + 63) >> 6, w0 = lane * per;
+            int sum = 0;
+            for (int c = 0; c < per; ++c) sum += w0 + c < W ? __popcll(krank[w0 + c]) : 0;
+            int inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(inc, d);
+                if (lane >= d) inc += t;
+            }
+            int run = inc - sum;
+            for (int c = 0; c < per; ++c)
+                if (w0 + c < W) { wpre[w0 + c] = run; run += __popcll(krank[w0 + c]); }
+        }
+        __syncthreads();
+        const unsigned long long* s1 = sorted1 + (size_t)b * n;
+        int* out = keep_idx + (size_t)b * n;
+        for (int g0 = 0; g0 < nv; g0 += 4 * (int)blockDim.x) {
+            unsigned long long key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * (int)blockDim.x + tid;
+                key[u] = s1[g < nv ? g : nv - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * (int)blockDim.x + tid;
+                if (g < nv) {
+                    const unsigned long long w = krank[g >> 6];
+                    if ((w >> (g & 63)) & 1ull) out[wpre[g >> 6] + __popcll(w & ((1ull << (g & 63)) - 1ull))] = (int)(unsigned)(key[u] & 0xffffffffull);
+                }
+            }
+        }
+        return;
+    }
+    // library-sort path: order 1 was overwritten; kept rows go to slot[global rank] (-1 elsewhere) and nms_compact_kernel follows
+    const int* ord = order + (size_t)b * n;
+    int* sl = slot + (size_t)b * n;
+    for (int q0 = 0; q0 < nv; q0 += 4 * (int)blockDim.x) {
+        int o[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                   // unconditional loads, four in flight; the store is the conditional part
+            const int q = q0 + u * (int)blockDim.x + tid, qc = q < nv ? q : nv - 1;
+            o[u] = ord[qc];
+            g[u] = gr[qc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * (int)blockDim.x + tid;
+            if (q < nv && ((keptl[q >> 6] >> (q & 63)) & 1ull)) sl[g[u]] = o[u];
+        }
+    }
 }
 
 static const bool g_nms_rocprim = getenv("YOLO_NMS_ROCPRIM") != nullptr;       // A/B switch: the library sorts instead of the chunk sort + rank merge
 
 struct NmsWs { int* nvalid; unsigned long long* row_any; int* order; SBox* sbox; unsigned long long* mask; size_t zero_bytes; size_t total;
                unsigned long long* keys_in; unsigned long long* keys_out; void* sort_tmp; size_t sort_tmp_bytes;
-               int* grank; int* blk_lo; int* blk_hi; unsigned long long* keptw; int* chunk_valid; unsigned long long* chunked;
+               int* grank; int* blk_lo; int* blk_hi; int* chunk_valid; unsigned long long* chunked;
                unsigned long long* sorted2; unsigned long long* near; };
 
 static size_t sort_tmp_bytes(int b, int n) {
@@ -1213,9 +1314,8 @@ static NmsWs carve(void* base, int b, int n) {
     NmsWs w;
     w.nvalid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1));
     w.row_any = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
-    w.keptw = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)(b > 0 ? b : 1) * W);
     w.chunk_valid = (int*)take(sizeof(int) * (size_t)(b > 0 ? b : 1) * SC_MAXCH);
-    w.zero_bytes = off;                                 // nvalid + row_any + keptw + chunk_valid are zeroed by one memset per call
+    w.zero_bytes = off;                                 // nvalid + row_any + chunk_valid: zeroed by one memset per call, except on the chunk-sort path (its kernels do it)
     w.order = (int*)take(sizeof(int) * (size_t)b * n);
     w.sbox = (SBox*)take(sizeof(SBox) * (size_t)b * n);
     w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)b * n * W);
@@ -1299,11 +1399,12 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
     const int W = ceil_div(n, 64);
     if ((size_t)(W + 2) * 8 > 60 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "nms: n = %d too large", n);
     if (b > 65535 || W > 65535) return fail(YOLO_ERR_UNSUPPORTED, "nms: grid too large");
-    if (hipMemsetAsync(w.nvalid, 0, w.zero_bytes, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
     int rc;
     const bool sorted_keys = n >= 2048 && n < (1 << 20) && b <= 2047;      // large n: sort the keys instead of counting
-    const size_t fixed = (size_t)W * 8 + 128;               // class-range scan: lo/hi, count, cuts ...
+    const size_t fixed = (size_t)W * 16 + 128;              // class-range scan: kept words, lo/hi, count, cuts ...
     int K = (int)((60 * 1024 - (long long)fixed) / (long long)((size_t)W * 8));   // ... and one removed[] array per wave, in LDS
+    const bool own_order = sorted_keys && K >= 1 && n <= SC * SC_MAXCH && !g_nms_rocprim;   // chunk sort + rank merge: they zero what they need
+    if (!own_order && hipMemsetAsync(w.nvalid, 0, w.zero_bytes, st) != hipSuccess) return fail(YOLO_ERR_LAUNCH, "nms: memset");
     K = K > 16 ? 16 : K;
     const dim3 gn(ceil_div(n, 256), b);
     if (sorted_keys && K < 1) {                             // n > ~245,000: score order only, the plain mask and scan
@@ -1317,21 +1418,23 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         rc = check_launch("nms_gather");
         if (rc) return rc;
     } else if (sorted_keys) {                               // + class-sorted rows
-        int* slot = (int*)w.keys_in;                        // kept boxes by global rank, -1 elsewhere
+        int* slot = (int*)w.keys_in;                        // kept boxes by global rank, -1 elsewhere (library-sort path only)
+        const unsigned long long* order1 = nullptr;         // order 1 when it survives to the scan (chunk-sort path)
         if (n <= SC * SC_MAXCH && !g_nms_rocprim) {          // both orders by the chunk sort + rank merge kernels (4 launches)
             const int nch = ceil_div(n, SC);
             const dim3 ga(nch, b), gb(nch * 8, b);
             hipLaunchKernelGGL(nms_chunksort_kernel<1>, ga, dim3(SC_THREADS), 0, st, boxes, (const unsigned long long*)nullptr, (const int*)nullptr, n,
                                obj_threshold, w.chunked, w.chunk_valid);
-            if (nch <= 3) hipLaunchKernelGGL(nms_merge1_kernel<2>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
-            else if (nch <= 5) hipLaunchKernelGGL(nms_merge1_kernel<4>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
-            else if (nch <= 9) hipLaunchKernelGGL(nms_merge1_kernel<8>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
-            else hipLaunchKernelGGL(nms_merge1_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, slot);
+            if (nch <= 3) hipLaunchKernelGGL(nms_merge1_kernel<2>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
+            else if (nch <= 5) hipLaunchKernelGGL(nms_merge1_kernel<4>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
+            else if (nch <= 9) hipLaunchKernelGGL(nms_merge1_kernel<8>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
+            else hipLaunchKernelGGL(nms_merge1_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
             rc = check_launch("nms order 1");
             if (rc) return rc;
             hipLaunchKernelGGL(nms_chunksort_kernel<2>, ga, dim3(SC_THREADS), 0, st, boxes, w.keys_out, w.nvalid, n, obj_threshold, w.chunked,
                                w.chunk_valid);
             // order 2 lands in a second array: order 1 (keys_out) is still being read by the chunk sort above
+            order1 = w.keys_out;
             unsigned long long* sorted2 = w.sorted2;
             if (nch <= 3) hipLaunchKernelGGL(nms_merge2_kernel<2>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
             else if (nch <= 5) hipLaunchKernelGGL(nms_merge2_kernel<4>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
@@ -1368,13 +1471,12 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         if (rc) return rc;
         const size_t lds = (size_t)K * W * 8 + fixed;
         hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(b), dim3(64 * K), lds, st, w.mask, w.keys_out, w.nvalid, w.row_any, w.blk_lo,
-                           w.blk_hi, n, W, w.keptw, keep_count, w.near);
+                           w.blk_hi, n, W, w.order, w.grank, slot, keep_count, w.near,
+                           own_order ? (const unsigned long long*)order1 : (const unsigned long long*)nullptr, keep_idx);
         rc = check_launch("nms_scan_classes");
         if (rc) return rc;
-        hipLaunchKernelGGL(nms_place_kernel, gn, dim3(256), 0, st, w.keptw, w.order, w.grank, w.nvalid, n, W, slot);
-        rc = check_launch("nms_place");
-        if (rc) return rc;
-        hipLaunchKernelGGL(nms_compact_kernel, dim3(b), dim3(256), 0, st, slot, w.nvalid, n, keep_idx);
+        if (own_order) return YOLO_OK;                  // the scan wrote keep_idx itself
+        hipLaunchKernelGGL(nms_compact_kernel, dim3(b), dim3(1024), 0, st, slot, w.nvalid, n, keep_idx);
         return check_launch("nms_compact");
     } else {
         hipLaunchKernelGGL(nms_rank_kernel, gn, dim3(256), 0, st, boxes, n, obj_threshold, center, w.order, w.sbox, w.nvalid);
