@@ -659,8 +659,9 @@ __global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict
 // (one per row, W words apart) - an uncoalesced, HBM-latency load on the scan's serial chain; here they are 512 contiguous bytes.
 constexpr int SCAN_NEAR = 3;
 
-// grid (S = 4, B, W), 64 threads: row block rb against column blocks rb + blockIdx.x, + S, ... while the class ranges overlap
-__global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
+// grid (1, B, W), MS_WAVES waves: wave w takes row block rb against column blocks rb + w, + MS_WAVES, ... while the class ranges overlap
+constexpr int MS_WAVES = 4;      // waves per workgroup = column-block stride (a 64-thread workgroup per (row block, stride) was dispatch-bound at 80 classes)
+__global__ __launch_bounds__(64 * MS_WAVES) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
                                                              const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
                                                              int W, float thr, unsigned long long* __restrict__ mask,
                                                              unsigned long long* __restrict__ row_any, unsigned long long* __restrict__ near) {
@@ -670,25 +671,31 @@ __global__ __launch_bounds__(64) void nms_mask_sorted_kernel(const SBox* __restr
     const int nv = nvalid[b];
     if (rb * 64 >= nv) return;
     const int nblk = (nv + 63) / 64;
-    __shared__ SBox cols[64];
+    // every wave works alone (its own staging buffer, its own trip count): no workgroup barrier below, only the wave's own
+    // program order (LDS operations of one wave execute in order; the wave barrier keeps the compiler from moving them).
+    // (Requesting the row's box, the class bounds and the first column block before nvalid is known was tried: the compiler
+    // sinks the loads below the early exit again and parks the column block in LDS - 24 -> 48 us at 80 classes.)
+    __shared__ SBox cols_all[MS_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SBox* cols = cols_all[wave];
     const SBox* sb = sbox + (size_t)b * n;
-    const int i = rb * 64 + threadIdx.x;
+    const int i = rb * 64 + lane;
     const bool active = i < nv;
     const SBox me = sb[active ? i : nv - 1];
     const int hi_r = blk_hi[(size_t)b * W + rb];
     const RowBounds rbnd = row_bounds(me, thr);
-    for (int cb = rb + blockIdx.x; cb < nblk; cb += gridDim.x) {
+    for (int cb = rb + blockIdx.x * MS_WAVES + wave; cb < nblk; cb += gridDim.x * MS_WAVES) {
         if (blk_lo[(size_t)b * W + cb] > hi_r) break;    // classes ascend: no later block can match either
-        const int j = cb * 64 + threadIdx.x;
-        __syncthreads();
-        if (j < nv) cols[threadIdx.x] = sb[j];
-        __syncthreads();
+        const int j = cb * 64 + lane;
+        __builtin_amdgcn_wave_barrier();
+        if (j < nv) cols[lane] = sb[j];
+        __builtin_amdgcn_wave_barrier();
         const int lim = nv - cb * 64 < 64 ? nv - cb * 64 : 64;
         const unsigned long long word = suppression_word(me, active, i, cols, lim, cb * 64, thr, sb + cb * 64, rbnd);
         if (active) mask[((size_t)b * n + i) * W + cb] = word;
-        if (active && cb - rb <= SCAN_NEAR) near[(((size_t)b * W + rb) * (SCAN_NEAR + 1) + (cb - rb)) * 64 + threadIdx.x] = word;
+        if (active && cb - rb <= SCAN_NEAR) near[(((size_t)b * W + rb) * (SCAN_NEAR + 1) + (cb - rb)) * 64 + lane] = word;
         const unsigned long long bal = __ballot(active && word != 0ull);
-        if (cb > rb && threadIdx.x == 0 && bal) atomicOr(&row_any[(size_t)b * W + rb], bal);
+        if (cb > rb && lane == 0 && bal) atomicOr(&row_any[(size_t)b * W + rb], bal);
     }
 }
 
@@ -1465,7 +1472,7 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
         // 4 blocks per row block: with many classes only the first 2-3 column blocks are in range and every further (empty)
         // block costs launch time (80 classes: 0.212 / 0.221 / 0.250 / 0.305 ms for 3 / 4 / 8 / 16), with 2 classes more
         // blocks help a little (1.16 / 1.12 / 1.05 / 1.02 ms)
-        hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(W < 4 ? W : 4, b, W), dim3(64), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
+        hipLaunchKernelGGL(nms_mask_sorted_kernel, dim3(1, b, W), dim3(64 * MS_WAVES), 0, st, w.sbox, w.nvalid, w.blk_lo, w.blk_hi, n,
                            W, (float)iou_threshold, w.mask, w.row_any, w.near);
         rc = check_launch("nms_mask_sorted");
         if (rc) return rc;
