@@ -154,17 +154,27 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
 
 def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
     from tests import golden_inputs as gi       # seeded box generators (data only)
+
+    def leg(batch):
+        t = torch.from_numpy(batch).to(device)
+        yt.nms_indices(t, 0.45, 0.5, "center")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            keep, count = yt.nms_indices(t, 0.45, 0.5, "center")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        return dt, float(count.float().mean())
+
     batch = np.stack([gi.boxes_uniform(n, nc, 1000 + b) for b in range(images)])
-    t = torch.from_numpy(batch).to(device)
-    yt.nms_indices(t, 0.45, 0.5, "center")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        keep, count = yt.nms_indices(t, 0.45, 0.5, "center")
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    return dict(boxes_per_s=images * n / dt, images=images, boxes_per_image=n, classes=nc, ms_per_batch=dt * 1e3,
-                kept_mean=float(count.float().mean())), batch
+    dt, kept = leg(batch)
+    out = dict(boxes_per_s=images * n / dt, images=images, boxes_per_image=n, classes=nc, ms_per_batch=dt * 1e3, kept_mean=kept)
+    # the fine-tune class count (2 classes: N^2 / 4 same-class pairs per image) and the clustered generator (SURVEY 8d Config 5 b)
+    for name, b2 in (("uniform_2_classes", np.stack([gi.boxes_uniform(n, 2, 1000 + b) for b in range(images)])),
+                     ("clustered_2_classes", np.stack([gi.boxes_clustered(n, 2, 1000 + b, jitter=0.15) for b in range(images)]))):
+        dt2, kept2 = leg(b2)
+        out[name] = dict(boxes_per_s=images * n / dt2, ms_per_batch=dt2 * 1e3, kept_mean=kept2)
+    return out, batch
 
 
 def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
