@@ -290,6 +290,42 @@ def test_nms_class_sorted_path_awkward_classes(yt):
     np.testing.assert_array_equal(keep[:int(count)].cpu().numpy(), opp.nms_indices_c(batch[0], 0.0, -1.0, "corner"))
 
 
+@pytest.mark.parametrize("case", ["skewed", "one_class", "two_classes_32768", "three_classes", "tiny_ranges"])
+def test_nms_class_scan_wave_teams(yt, case):
+    """With at most 8 class ranges per image the class scan gives every range a team of waves (a leader on the serial chain,
+    helpers for the far pushes): one class (15 helpers), 2 classes at 32,768 boxes (two column slices per helper pass), 3
+    classes (teams of 5), a skewed histogram (one class with 90 % of the boxes, the rest sharing multi-class ranges, so the
+    never-written-word checks of the team path are live), and ranges of one or two 64-row blocks. Dense overlap (clustered
+    boxes) so that most rows are suppressed through far pushes. Kept indices exactly the C oracle's."""
+    rng = np.random.Generator(np.random.PCG64(len(case) * 1009))
+    if case == "skewed":
+        imgs = []
+        for b in range(3):
+            bx = gi.boxes_clustered(6000, 1, 800 + b, n_gt=40, jitter=0.3)
+            bx[:, 5] = np.where(rng.random(6000) < 0.9, 0.0, rng.integers(1, 6, 6000)).astype(F32)
+            imgs.append(bx)
+    elif case == "one_class":
+        imgs = [gi.boxes_clustered(5000, 1, 810, n_gt=25, jitter=0.4), gi.boxes_uniform(5000, 1, 811)]
+    elif case == "two_classes_32768":
+        imgs = [gi.boxes_clustered(32768, 2, 820, n_gt=400, jitter=0.3)]
+    elif case == "three_classes":
+        imgs = [gi.boxes_clustered(7000, 3, 830 + b, n_gt=30, jitter=0.3) for b in range(2)]
+    else:
+        imgs = []
+        for b in range(4):                                   # 2 .. 5 classes, 70 .. 200 valid boxes each among 2,048
+            bx = gi.boxes_clustered(2048, 2 + b, 840 + b, n_gt=10, jitter=0.3)
+            bx[:, 4] = np.where(rng.random(2048) < 0.06 + 0.05 * b, 0.6 + 0.4 * rng.random(2048), 0.1).astype(F32)
+            imgs.append(bx)
+    for bx in imgs:
+        bx[:, 4] = np.maximum(bx[:, 4], F32(0.05))
+    batch = np.stack(imgs)
+    keep, count = yt.nms_indices(torch.from_numpy(batch).cuda(), 0.45, 0.5, "center")
+    for b in range(len(imgs)):
+        want = opp.nms_indices_c(batch[b], 0.45, 0.5, "center")
+        assert int(count[b]) == len(want)
+        np.testing.assert_array_equal(keep[b, :int(count[b])].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("thr", [0.05, 0.3, 0.45, 0.5, 0.75, 0.95])
 @pytest.mark.parametrize("scale", [1.0, 416.0, 1.0e4])
 def test_nms_candidate_bounds_pairs_at_the_threshold(yt, thr, scale):
