@@ -2272,4 +2272,163 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
     return dispatch_h<_Float16>(a, d->ksize, d->stride, bn, s);
 }
 
+// ---- the network's first block on the matrix cores, 16-bit output (3 -> 32 channels, 3x3, stride 1, pad 1) ---------------
+// stem_f32.hip does this layer on the vector ALUs: 432 packed FMAs per pixel whose 864 weights arrive through the scalar cache -
+// 224 us at B = 32, 416^2, against ~75 us for its bytes (66 MB of fp32 NCHW input, 354 MB of 16-bit NHWC output). For a 16-bit
+// output the arithmetic the reference's autocast does (model.py:80-86 under train.py:53) IS a 16-bit matrix product: input and
+// weights rounded to the 16-bit type, fp32 accumulation. So: K = 27 taps padded to 32 = two v_mfma_f32_32x32x16 per 32 pixels.
+//   * operand swap (cdna_hip_programming.md T21): the WEIGHTS are the A operand (M = the 32 output channels) and the pixels the
+//     B operand (N = 32 consecutive pixels), so D = [channel][pixel]: a lane owns pixel (lane & 31) and channels 8g + 4h + {0..3}
+//     (h = lane >> 5), and one v_permlane32_swap per register pair leaves it with 8 consecutive channels = one 16-byte store;
+//   * B operand straight from global memory: lane (pixel, h) loads the 16 taps k = 16 q + 8 h + e (q = 0..1, e = 0..7) of its
+//     pixel - no LDS, no barrier; the 9x overlap between neighbouring pixels is absorbed by L1 / L2 as in the vector kernel.
+//     Tap k = (c * 3 + dh) * 3 + dw (the order of the packed weights, stem_pack_kernel); k >= 27 is zero on both sides;
+//   * a 32-pixel tile none of whose pixels touches the image border (85 % of them at 416^2) takes loads at fixed per-lane
+//     offsets with no masking at all; the others mask per tap;
+//   * the weights (two A operands), scale and shift live in registers for the wave's ST_TILES tiles;
+//   * every input element is the centre tap of exactly one pixel: the input NaN guard of model.py:175 rides on taps 4, 13, 22.
+constexpr int ST_TILES = 8;              // 32-pixel tiles per wave
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void stem3x3_mfma_h16(const float* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        unsigned short* __restrict__ y, int H, int W, long long total, int y_ld,
+                                                        int y_off, unsigned mg_HW, unsigned mg_W, int* nan_flag) {
+    typedef typename HTraits<T>::vec vec;
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int HW = H * W;
+    // this lane's 16 taps: value offset relative to its pixel's channel-0 element, and whether the tap exists (k < 27)
+    int toff[16];
+    bool tval[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = (e >> 3) * 16 + hf * 8 + (e & 7);
+        const int c = k / 9, r = k - 9 * c, dh = r / 3, dw = r - 3 * dh;
+        tval[e] = k < 27;
+        toff[e] = tval[e] ? c * HW + (dh - 1) * W + (dw - 1) : 0;
+    }
+    // A operands: weights of channel `col`, taps 16 q + 8 hf + e
+    vec wa[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 pk;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int k0 = q * 16 + hf * 8 + 2 * e2;
+            const float w0 = k0 < 27 ? wt[k0 * 32 + col] : 0.f, w1 = k0 + 1 < 27 ? wt[(k0 + 1) * 32 + col] : 0.f;
+            pk[e2] = pack2<T>(w0, w1);
+        }
+        wa[q] = __builtin_bit_cast(vec, pk);
+    }
+    __shared__ __attribute__((aligned(16))) float sstab[64];        // scale[32], shift[32]: read back per tile (32 registers otherwise)
+    if (threadIdx.x < 64) sstab[threadIdx.x] = threadIdx.x < 32 ? scale[threadIdx.x] : shift[threadIdx.x - 32];
+    __syncthreads();
+    bool bad_in = false, bad_out = false;
+    const long long tile0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ST_TILES;
+    // A tile's 16 loads are issued together and nothing in `fetch` waits for them: a tap outside the image reads the pixel's own
+    // element instead and is zeroed in `finish` through a bit mask (so is a tap k >= 27).
+    unsigned tmask = 0;                                     // bit e: tap e exists
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tmask |= tval[e] ? (1u << e) : 0u;
+    struct Tile { float v[16]; int p; unsigned okm; bool live; };
+    auto fetch = [&](int it, Tile& t) {
+        const long long first = (tile0 + it) * 32;
+        const long long p_raw = (first < total ? first : 0) + col;          // past the end: any valid pixel, never used
+        t.live = first < total && p_raw < total;
+        t.p = (int)(p_raw < total ? p_raw : total - 1);
+        const int n = fdiv(t.p, mg_HW, HW), rem = t.p - n * HW;
+        const int h = fdiv(rem, mg_W, W), w = rem - h * W;
+        // 32-bit byte offsets from the scalar base (the launcher checks the input is below 4 GB): one VGPR per address, not two
+        const unsigned pxo = (unsigned)(n * 3 * HW + rem) * 4u;              // channel 0 of this pixel
+        const char* xb = reinterpret_cast<const char*>(x);
+        unsigned off[16];
+        t.okm = tmask;
+        const bool border = h == 0 || h == H - 1 || w == 0 || w == W - 1;
+        if (__ballot(border) == 0ull) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) off[e] = pxo + (unsigned)(toff[e] * 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = (e >> 3) * 16 + hf * 8 + (e & 7);
+                const int c = k / 9, r = k - 9 * c, dh = r / 3, dw = r - 3 * dh;
+                const bool ok = (unsigned)(h + dh - 1) < (unsigned)H && (unsigned)(w + dw - 1) < (unsigned)W;
+                off[e] = pxo + (ok ? (unsigned)(toff[e] * 4) : 0u);
+                t.okm &= ok ? ~0u : ~(1u << e);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t.v[e] = *reinterpret_cast<const float*>(xb + (size_t)off[e]);
+    };
+    auto finish = [&](Tile& t) {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)                        // all ones or zero from bit e of the mask: v_bfe_i32 + v_and
+            v[e] = __uint_as_float(__float_as_uint(t.v[e]) & (unsigned)__builtin_amdgcn_sbfe((int)t.okm, e, 1));
+        // centre taps: k = 4 (hf 0, e 4), 13 (hf 1, e 5), 22 (hf 0, e 14)
+        if (t.live) bad_in |= hf == 0 ? (v[4] != v[4]) || (v[14] != v[14]) : (v[5] != v[5]);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 pk;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) pk[e2] = pack2<T>(v[q * 8 + 2 * e2], v[q * 8 + 2 * e2 + 1]);
+            acc = HTraits<T>::mfma(wa[q], __builtin_bit_cast(vec, pk), acc);
+        }
+        float o[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {                    // channels 8 g4 + 4 hf + {0..3}
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(sstab + 8 * g4 + 4 * hf);
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(sstab + 32 + 8 * g4 + 4 * hf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * g4 + e] = act_c<ACT>(acc[4 * g4 + e] * sc4[e] + sh4[e]);
+        }
+        unsigned short* dst = y + (size_t)t.p * y_ld + y_off + 8 * hf;
+        bool bad = false;
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * kp + e]), __float_as_uint(o[8 * kp + 4 + e]), false, false);
+                g[e] = __uint_as_float(sw[0]);              // lanes 0-31: channels 16 kp + 0..7 | lanes 32-63: 16 kp + 8..15
+                g[4 + e] = __uint_as_float(sw[1]);
+            }
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bad |= __builtin_isunordered(g[2 * e], g[2 * e + 1]);
+                ov[e] = pack2<T>(g[2 * e], g[2 * e + 1]);
+            }
+            if (t.live) *reinterpret_cast<u32x4*>(dst + 16 * kp) = ov;
+        }
+        bad_out |= bad && t.live;
+    };
+    Tile A, B;
+    fetch(0, A);
+#pragma unroll 1
+    for (int it = 0; it < ST_TILES; it += 2) {              // tile it + 1 is requested before tile it is multiplied and stored
+        fetch(it + 1, B);
+        finish(A);
+        fetch(it + 2, A);                                   // tile ST_TILES: fetched (a valid address), never finished
+        finish(B);
+    }
+    if (bad_in) atomicOr(nan_flag, 1);                       // NaN in the INPUT tensor (model.py:175)
+    if (bad_out) atomicOr(nan_flag, 2);
+}
+
+int stem_h16_launch(const float* x, const float* wt, const float* scale, const float* shift, void* y, int n, int h, int w, int y_ld,
+                    int y_off, int act, int dtype, int* nan_flag, hipStream_t s) {
+    const long long total = (long long)n * h * w;
+    if (total * 12 >= (1ll << 32)) return fail(YOLO_ERR_UNSUPPORTED, "stem (16-bit): input of 4 GB or more");
+    const long long waves = (total + 32 * ST_TILES - 1) / (32 * ST_TILES);
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const unsigned mg_HW = magic_of(h * w), mg_W = magic_of(w);
+#define YOLO_STEM_LAUNCH(T)                                                                                                       \
+    YOLO_SWITCH_ACT(act, hipLaunchKernelGGL((stem3x3_mfma_h16<T, ACT>), dim3(grid), dim3(256), 0, s, x, wt, scale, shift,          \
+                                            (unsigned short*)y, h, w, total, y_ld, y_off, mg_HW, mg_W, nan_flag))
+    if (dtype == YOLO_BF16) { YOLO_STEM_LAUNCH(__bf16); } else { YOLO_STEM_LAUNCH(_Float16); }
+#undef YOLO_STEM_LAUNCH
+    return check_launch("stem3x3_mfma_h16");
+}
+
 }  // namespace yolo

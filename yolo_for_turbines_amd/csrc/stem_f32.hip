@@ -179,6 +179,10 @@ int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scal
         return fail(YOLO_ERR_UNSUPPORTED, "stem: only 3 -> 32 channels, y_ld/y_off multiples of 16 bytes");
     const long long total = (long long)n * h * w;
     if (total > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "stem: too many pixels");
+    // 16-bit output: the matrix-core kernel of conv_h16.hip (input and weights rounded to the 16-bit type, as autocast does)
+    static const bool valu_stem = getenv("YOLO_STEM_VALU") != nullptr;      // A/B switch: keep the vector kernel
+    if (dtype != YOLO_F32 && !valu_stem)
+        return stem_h16_launch(x_nchw, w_k_major, scale, shift, y, n, h, w, y_ld, y_off, act, dtype, nan_flag, (hipStream_t)stream);
     hipLaunchKernelGGL((stem3x3_f32<32>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
                        w_k_major, scale, shift, y, n, h, w, y_ld, y_off, act, dtype, nan_flag);
     return check_launch("stem3x3_f32");
