@@ -1435,3 +1435,60 @@ def test_dma_conv_kernels_edge_shapes(yt, case, dtype):
     keep = torch.ones(y_ld, dtype=torch.bool)
     keep[y_off:y_off + cout] = False
     assert torch.equal(got[..., keep], y0[..., keep])                           # neighbouring channels of the buffer untouched
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 32, 32), (3, 37, 45), (2, 5, 3), (1, 1, 70), (2, 96, 96), (1, 416, 416)])
+def test_stem_block_on_the_matrix_cores(yt, shape, dtype):
+    """yolo_stem_fwd with a 16-bit output (stem3x3_mfma_h16): widths that are not multiples of the 32-pixel tile (tiles that wrap
+    around rows and images), images narrower than a tile, a pixel count that is not a multiple of the wave's 8 tiles, every
+    border, ld / off views, the activation, and the two NaN guards (input centre taps; an Inf input gives +-Inf / NaN like the
+    reference, never a NaN from a masked or padded tap). Reference: fp64 convolution of the operands rounded to the 16-bit type
+    (what the reference's autocast conv multiplies), so the only error left is fp32 accumulation order + the final rounding."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    N, H, W = shape
+    code, tdt, tol = {"bf16": (L.BF16, torch.bfloat16, 8e-3), "fp16": (L.F16, torch.float16, 1.5e-3)}[dtype]
+    g = torch.Generator().manual_seed(31 * H + W + N)
+    lib, dev = L.lib(), torch.device("cuda:0")
+    x = torch.rand((N, 3, H, W), generator=g)
+    w = torch.randn((32, 3, 3, 3), generator=g) * 0.3
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    y_ld, y_off = 48, 16
+    y0 = torch.randn((N, H, W, y_ld), generator=g).to(tdt)
+    xd, wd, sd, shd, yd = x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), y0.clone().to(dev)
+    wp = torch.empty(27 * 32, dtype=torch.float32, device=dev)
+    st = L.current_stream()
+    L.check(lib.yolo_stem_pack(wd.data_ptr(), wp.data_ptr(), 32, st))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(inp, out):
+        L.check(lib.yolo_stem_fwd(inp.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), out.data_ptr(), N, H, W, 32, y_ld, y_off,
+                                  1, code, flag.data_ptr(), st), "yolo_stem_fwd")
+        torch.cuda.synchronize()
+
+    run(xd, yd)
+    assert int(flag.item()) == 0
+    ref = F.conv2d(x.to(tdt).double(), w.to(tdt).double(), stride=1, padding=1)
+    ref = F.leaky_relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1), 0.1).permute(0, 2, 3, 1)
+    got = yd.cpu()
+    err = float((got[..., y_off:y_off + 32].double() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err
+    keep = torch.ones(y_ld, dtype=torch.bool)
+    keep[y_off:y_off + 32] = False
+    assert torch.equal(got[..., keep], y0[..., keep])                           # the rest of the buffer untouched
+    # an Inf in a corner: its 2x2 neighbourhood becomes +-Inf (or NaN where +Inf and -Inf meet), everything else stays finite
+    xi = x.clone()
+    xi[0, 1, 0, 0] = float("inf")
+    yi = y0.clone().to(dev)
+    flag.zero_()
+    run(xi.to(dev), yi)
+    outi = yi.cpu()[..., y_off:y_off + 32].float()
+    far = torch.ones((N, H, W), dtype=torch.bool)
+    far[0, :2, :2] = False
+    assert torch.isfinite(outi[far]).all() and not torch.isfinite(outi[0, 0, 0]).all()
+    # a NaN anywhere in the input raises bit 0 of the flag (model.py:175)
+    xn = x.clone()
+    xn[N - 1, 2, H - 1, W - 1] = float("nan")
+    flag.zero_()
+    run(xn.to(dev), yi)
+    assert int(flag.item()) & 1
