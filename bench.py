@@ -356,6 +356,7 @@ def main():
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--torch-sgd", action="store_true", help="fine-tune legs: torch.optim.SGD instead of yt.SGD (same update, ~19 launches)")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (tuning)")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch times to stderr")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
@@ -430,9 +431,13 @@ def main():
         grids = [args.size // 32, args.size // 16, args.size // 8]
         sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(device)
         tg = [torch.from_numpy(t).to(device) for t in gi.synth_targets(args.batch, args.size, args.train_classes, anchors, 3 + rank)]
-        opt = torch.optim.SGD(tm.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+        # train.py:171-172: SGD(model.parameters(), lr, momentum, weight_decay). yt.SGD is the same optimizer (a torch.optim.SGD
+        # subclass: same state, same bits per step, tests/test_gpu_parity.py::test_sgd_step_same_bits_as_torch) with the update
+        # as one HIP launch; --torch-sgd times PyTorch's own multi-tensor implementation instead
+        opt = (torch.optim.SGD if args.torch_sgd else yt.SGD)(tm.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
         n_par = sum(p.numel() for p in tm.parameters())
-        step_desc = "zero_grad + forward(train-mode BN) + 3 x per-scale loss + backward + SGD"
+        step_desc = ("zero_grad + forward(train-mode BN) + 3 x per-scale loss + backward + SGD (" +
+                     ("torch.optim.SGD" if args.torch_sgd else "yt.SGD: one launch, same bits as torch.optim.SGD") + ")")
 
         def make_step(lf, autocast_dtype):              # train.py:41-69: zero_grad, autocast forward, 3 x loss, backward, SGD
             def train_step():

@@ -215,6 +215,16 @@ int yolo_loss_fwd(const float* pred, const int64_t* strides5, const float* targe
 int yolo_loss_bwd(const float* pred, const int64_t* strides5, const float* target, const float* anchors_3x2, int b, int g, int nc,
                   const float* counts2, const float* grad_losses4, float* dpred, void* stream);
 
+/* ---- optimizer step (code/train.py:171-172 torch.optim.SGD(model.parameters(), lr, momentum, weight_decay); :68 step) ---- */
+/* One launch over every parameter tensor; the same bits as torch.optim.SGD's default implementation (each of its passes
+ * rounds a + alpha * b once). items (device): n_items x yolo_sgd_item; an item with g == NULL is skipped; n < 0 marks a
+ * momentum buffer that does not exist yet (first step: buf = g + wd * p). chunks (device): n_chunks x {item index, first
+ * element}, one per yolo_sgd_chunk_elems() elements of every item. */
+typedef struct yolo_sgd_item { float* p; const float* g; float* buf; long long n; } yolo_sgd_item;
+int yolo_sgd_chunk_elems(void);
+int yolo_sgd_step(const void* items_dev, const int32_t* chunks_dev, int n_chunks, float lr, float momentum, float dampening,
+                  float weight_decay, int nesterov, int maximize, void* stream);
+
 /* ---- post-processing ------------------------------------------------------------------- */
 /* Replaces cells_to_boxes (utils.py:86-148) for one scale.
  * pred: (B,3,g,g,5+nc) fp32 addressed through element strides s[5] (so the reference's permuted

@@ -1492,3 +1492,42 @@ def test_stem_block_on_the_matrix_cores(yt, shape, dtype):
     flag.zero_()
     run(xn.to(dev), yi)
     assert int(flag.item()) & 1
+
+
+@pytest.mark.parametrize("cfg", [dict(lr=1e-4, momentum=0.9, weight_decay=5e-4), dict(lr=0.01), dict(lr=0.05, momentum=0.8, dampening=0.1),
+                                 dict(lr=0.02, momentum=0.9, weight_decay=1e-3, nesterov=True), dict(lr=0.03, momentum=0.5, maximize=True),
+                                 dict(lr=0.01, weight_decay=0.1)])
+def test_sgd_step_same_bits_as_torch(yt, cfg):
+    """yt.SGD (one HIP launch over all parameters) against torch.optim.SGD as train.py:171-172 constructs it: identical bits in
+    every parameter and momentum buffer after each of four steps (the first one creates the buffers), tensor sizes that are not
+    multiples of the 4,096-element chunk or of four, a parameter that never gets a gradient, one that gets it only from the
+    third step on, a view that is not 16-byte aligned, and a state_dict round trip into the PyTorch optimizer."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32, 3, 3), (32,), (1,), (255, 1024, 1, 1), (4097,), (3, 5, 7), (1030,)]
+    base = torch.randn(1031, generator=g).cuda()
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)]
+        ps.append(torch.nn.Parameter(base.clone()[1:]))                 # storage offset of 4 bytes: the scalar path
+        return ps
+    pa, pb = make(), make()
+    oa, ob = yt.SGD(pa, **cfg), torch.optim.SGD(pb, **cfg)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 2 or (i == 4 and step < 2):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=torch.Generator().manual_seed(100 * step + i)).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a, b), (step, i)
+            ba, bb = oa.state[a].get("momentum_buffer"), ob.state[b].get("momentum_buffer")
+            assert (ba is None) == (bb is None) and (ba is None or torch.equal(ba, bb)), (step, i)
+    oc = torch.optim.SGD(make(), **cfg)
+    oc.load_state_dict(oa.state_dict())                                  # utils.py:383-416 checkpoints load either way
+    assert oc.state_dict()["param_groups"][0]["lr"] == cfg["lr"]
+    cpu_p = torch.nn.Parameter(torch.zeros(4))
+    cpu_p.grad = torch.ones(4)
+    with pytest.raises(TypeError):                                       # no CPU fallback
+        yt.SGD([cpu_p], lr=0.1).step()

@@ -161,3 +161,34 @@ def test_second_train_forward_before_backward_is_refused(yt):
         l1.backward()
     l2.backward()                                                   # the newest forward's backward is fine
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_training_with_the_fused_sgd_step_follows_torch_sgd(yt, ac):
+    """Three fine-tune steps with yt.SGD (parameters written through raw pointers by one HIP launch) and three with
+    torch.optim.SGD from the same start: every parameter and running statistic bit-equal after each step. Catches an update
+    the engine does not notice (it re-packs a weight when its version counter moves), not only the update arithmetic."""
+    sd, x, tg, sa = _case(311)
+    lf = yt.FusedYOLOLoss()
+
+    def run(opt_cls):
+        m = yt.YOLOv3(num_classes=NC, activation="leaky_relu")
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        m = m.cuda().train()
+        opt = opt_cls(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        snaps = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+                preds = m(x)
+                loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+            loss.backward()
+            opt.step()
+            snaps.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+        return snaps
+
+    a, b = run(yt.SGD), run(torch.optim.SGD)
+    for step in range(3):
+        for k in a[step]:
+            assert torch.equal(a[step][k], b[step][k]), (step, k)
+    assert not torch.equal(a[2]["layers.0.conv.weight"], a[0]["layers.0.conv.weight"])

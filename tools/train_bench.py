@@ -29,7 +29,7 @@ sa = (torch.tensor(anchors) * torch.tensor(grids).view(3, 1, 1)).to(dev)
 x = torch.rand(a.batch, 3, a.size, a.size, device=dev)
 tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(a.batch, a.size, a.classes, anchors, 3)]
 lf = yt.FusedYOLOLoss() if (a.fused_loss or a.graph) else yt.YOLOLoss()
-opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
+opt = (torch.optim.SGD if os.environ.get('TORCH_SGD') else yt.SGD)([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
 
 def step(timing=None):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -54,7 +54,7 @@ if a.graph:
     # whole-step capture: forward(train) + loss + backward + SGD as ONE graph launch (no per-kernel launch cost).
     # Needs the per-forward NaN guard's host sync off and capturable optimizer state.
     m._engine.nan_check = False
-    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    opt = (torch.optim.SGD if os.environ.get('TORCH_SGD') else yt.SGD)([p for p in m.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=5e-4)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
