@@ -60,12 +60,18 @@ def timed_steps(step, steps: int, warmup: int, dist=None, device=None):
             dist.barrier()
         _sync()
 
+    import gc
+    gc.collect()                                         # no collector pause inside the timed region
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     _sync()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     barrier()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
