@@ -208,12 +208,22 @@ class PackedBlock:
         are made of. Versions only see writes PyTorch dispatched; tensors this library writes through raw pointers (the
         BatchNorm running statistics in a train-mode forward, every parameter in a HIP-graph replay) are covered by
         ``ModelState.mark_unfolded`` / ``invalidate`` instead."""
-        def st(ts):
-            return tuple((t.data_ptr(), t._version) for t in ts)
+        w, rest = PackedBlock.stamp_tensors(block)
+        return ((w.data_ptr(), w._version),), tuple((t.data_ptr(), t._version) for t in rest)
+
+    @staticmethod
+    def stamp_tensors(block):
+        """(conv weight, the tensors behind scale / shift). Straight from the modules' dictionaries: nn.Module.__getattr__
+        costs ~1 us per hop, and 75 blocks x 10 hops per forward was 0.5 ms of host time in front of the first launch -
+        the GPU sat idle for it after every forward's NaN-flag sync (a 320 us gap per 3.5 ms bf16 forward in the trace)."""
+        mods = block._modules
+        conv = mods["conv"]
+        w = conv._parameters["weight"]
         if block.batch_norm_act:
-            bn = block.batch_norm
-            return st([block.conv.weight]), st([bn.weight, bn.bias, bn.running_mean, bn.running_var])
-        return st([block.conv.weight]), st([block.conv.bias])
+            bn = mods["batch_norm"]
+            pr, bf = bn._parameters, bn._buffers
+            return w, (pr["weight"], pr["bias"], bf["running_mean"], bf["running_var"])
+        return w, (conv._parameters["bias"],)
 
     def refresh(self, block, stream, fold_bn=True, conv_packed=False, pack=True):
         """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold.
@@ -361,6 +371,8 @@ class ModelState:
         # keyed by the block MODULE (weakly): an id()-keyed cache could hand a new block the packed
         # weights of a dead one that happened to reuse its address and parameter storage
         self._packed = weakref.WeakKeyDictionary()
+        self._gen = 0                     # bumped whenever packed state is declared out of date by hand (invalidate, mark_unfolded)
+        self._fast = {}                   # (id(blocks), device, dtype, fold_bn) -> (gen, blocks, [(tensor, version, address)])
         self._plans = {}
         self.nan_check = True
         self.tile_override = None
@@ -411,6 +423,8 @@ class ModelState:
         return torch.float32
 
     def invalidate(self, drop_plans=False):
+        self._gen += 1
+        self._fast.clear()
         for per_dev in self._packed.values():
             for pk in per_dev.values():
                 pk.stamp = None
@@ -432,6 +446,30 @@ class ModelState:
         return pk
 
     def refresh_weights(self, blocks, device, stream, dtype="fp32", fold_bn=True):
+        # fast path: nothing this library or PyTorch wrote since the last full check of this very list of blocks -
+        # one flat walk over (tensor, version, address) instead of rebuilding 75 pairs of stamps
+        fkey = (id(blocks), device.index, dtype, fold_bn)
+        fast = self._fast.get(fkey)
+        if fast is not None and fast[0] == self._gen and fast[1] is blocks:
+            for t, ver, ptr in fast[2]:
+                if t._version != ver or t.data_ptr() != ptr:
+                    break
+            else:
+                return
+        self._refresh_weights_slow(blocks, device, stream, dtype, fold_bn)
+        flat = []
+        for blk in blocks:
+            w, rest = PackedBlock.stamp_tensors(blk)
+            if blk.conv._parameters["weight"] is not w:
+                break
+            flat.append((w, w._version, w.data_ptr()))
+            flat.extend((t, t._version, t.data_ptr()) for t in rest)
+        else:
+            if len(self._fast) > 64:
+                self._fast.clear()
+            self._fast[fkey] = (self._gen, blocks, flat)
+
+    def _refresh_weights_slow(self, blocks, device, stream, dtype="fp32", fold_bn=True):
         stale, refold = [], []
         for blk in blocks:
             pk = self.packed(blk, device, dtype)
@@ -461,6 +499,7 @@ class ModelState:
     def mark_unfolded(self, blocks):
         """The BatchNorm running statistics of ``blocks`` were just written by a kernel (train-mode forward): every folded
         scale / shift made from them, in any dtype, is out of date — whether or not the block was stale before."""
+        self._gen += 1
         for blk in blocks:
             per_dev = self._packed.get(blk)
             if per_dev:
