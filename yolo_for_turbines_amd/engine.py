@@ -339,6 +339,7 @@ class Plan:
                 self.stem_pk = pk
             if op["pred"] is not None:
                 self.pred_ops[op["pred"]] = (i, op["Ho"], blk.conv.out_channels // 3)
+        self.blocks0 = self.blocks[:1]    # the stem block alone (its own freshness check, see ModelState.forward)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.dropped = False
 
@@ -535,12 +536,19 @@ class ModelState:
                 if dt != "fp32" and plan.stem is None:
                     raise NotImplementedError("the 16-bit path needs the 3->32 stem block as the first layer")
             self._remember(key, plan)
-            self.refresh_weights(plan.blocks, x.device, stream, dt)
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
                 xin = xin.float().contiguous()
             plan.nan_flag.zero_()
-            plan.load_input(xin, stream)
+            if plan.stem is not None:
+                # the first block only needs ITS weights: check those, get the stem kernel going, and walk the other 74
+                # blocks while it runs (the GPU is idle from the previous forward's flag sync until this launch)
+                self.refresh_weights(plan.blocks0, x.device, stream, dt)
+                plan.load_input(xin, stream)
+                self.refresh_weights(plan.blocks, x.device, stream, dt)
+            else:
+                self.refresh_weights(plan.blocks, x.device, stream, dt)
+                plan.load_input(xin, stream)
             preds = []
             for k in range(plan.prog.n_pred):
                 i, g, c3 = plan.pred_ops[k]
