@@ -529,9 +529,8 @@ def main():
                     [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
         sa5 = [torch.tensor(a).to(device) * gsz for a, gsz in zip(anchors5, (19, 38, 76))]
 
-        def step5():
-            with torch.no_grad():
-                yt.detect(m5(x5), sa5, 0.45, 0.5, "center")
+        def step5():                                    # forward + decode + NMS, one host sync per batch (the NaN guards of the forward)
+            yt.detect_images(m5, x5, sa5, 0.45, 0.5, "center")
         t5 = ydist.timed_steps(step5, 10, 2, dist, device)
         cfg5 = {"workload": "BASELINE configs[4] per-GPU shape: batch 16, 608x608 fp16 forward + decode (22,743 boxes/image) + per-image NMS",
                 "value": round(16 * world * 10 / t5, 2), "unit": "images/s", "ms_per_step": round(t5 / 10 * 1e3, 3)}

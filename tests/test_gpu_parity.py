@@ -1531,3 +1531,39 @@ def test_sgd_step_same_bits_as_torch(yt, cfg):
     cpu_p.grad = torch.ones(4)
     with pytest.raises(TypeError):                                       # no CPU fallback
         yt.SGD([cpu_p], lr=0.1).step()
+
+
+def test_detect_images_one_sync_same_results_same_exceptions(yt):
+    """detect_images(model, x, ...) = detect(model(x), ...) with the forward's NaN guards read after the post-processing is
+    enqueued: identical boxes / kept indices / counts, the reference's exceptions for a NaN input (model.py:175) and for a
+    NaN produced by a layer (model.py:183-184), and the engine back in its normal mode afterwards (also after a raise)."""
+    c = gi.NET_CASES["nc80_s96_b2_leaky"]
+    m = _model(yt, c)
+    x = onet.synth_input(78, 3, 128).cuda()
+    anchors = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],
+               [(0.02, 0.03), (0.04, 0.07), (0.08, 0.06)]]
+    sa = [torch.tensor(a).cuda() * g for a, g in zip(anchors, (4, 8, 16))]
+    with torch.no_grad():
+        b0, k0, c0 = yt.detect(m(x), sa, 0.45, 0.5, "center")
+    b1, k1, c1 = yt.detect_images(m, x, sa, 0.45, 0.5, "center")
+    assert torch.equal(b0, b1) and torch.equal(c0, c1)
+    for i in range(3):
+        assert torch.equal(k0[i, :int(c0[i])], k1[i, :int(c1[i])])
+    xn = x.clone()
+    xn[1, 0, 5, 5] = float("nan")
+    with pytest.raises(AssertionError):
+        yt.detect_images(m, xn, sa, 0.45, 0.5, "center")
+    assert m._engine._defer_nan is False and m._engine._pending_flag is None
+    with pytest.raises(AssertionError):                                  # and the plain forward still guards by itself
+        with torch.no_grad():
+            m(xn)
+    w = m.layers[3].conv.weight if hasattr(m.layers[3], "conv") else next(m.layers[3].parameters())
+    with torch.no_grad():
+        old = w.detach().clone()
+        w.fill_(float("inf"))                                            # inf * 0-ish activations -> NaN inside the network
+    with pytest.raises(ValueError, match="Nan in layer"):
+        yt.detect_images(m, x, sa, 0.45, 0.5, "center")
+    with torch.no_grad():
+        w.copy_(old)
+    b2, k2, c2 = yt.detect_images(m, x, sa, 0.45, 0.5, "center")
+    assert torch.equal(b0, b2) and torch.equal(c0, c2)

@@ -372,6 +372,8 @@ class ModelState:
         # keyed by the block MODULE (weakly): an id()-keyed cache could hand a new block the packed
         # weights of a dead one that happened to reuse its address and parameter storage
         self._packed = weakref.WeakKeyDictionary()
+        self._defer_nan = False           # detect_images(): the forward leaves its NaN flag for the caller to read
+        self._pending_flag = None
         self._gen = 0                     # bumped whenever packed state is declared out of date by hand (invalidate, mark_unfolded)
         self._fast = {}                   # (id(blocks), device, dtype, fold_bn) -> (gen, blocks, [(tensor, version, address)])
         self._plans = {}
@@ -556,15 +558,21 @@ class ModelState:
                 plan.table[i].y = out.data_ptr()
                 preds.append(out)
             plan.launch(stream)
-            if self.nan_check:
-                flag = int(plan.nan_flag.item())                  # the one host sync of a forward
-                assert not (flag & 1), "NaN in the input tensor"  # model.py:175
-                if flag & 2:
-                    raise ValueError("Nan in layer")              # model.py:183-184
+            if self.nan_check and not self._defer_nan:
+                self.raise_on_nan(plan.nan_flag)                  # the one host sync of a forward
+            elif self.nan_check:
+                self._pending_flag = plan.nan_flag                # detect_images(): checked after the post-processing is enqueued
             hd = self.head_dtype()
             if hd != torch.float32:
                 preds = [t.to(hd) for t in preds]
         return preds
+
+    @staticmethod
+    def raise_on_nan(flag_tensor):
+        flag = int(flag_tensor.item())
+        assert not (flag & 1), "NaN in the input tensor"          # model.py:175
+        if flag & 2:
+            raise ValueError("Nan in layer")                      # model.py:183-184
 
 
 # ------------------------------------------------------------------ stand-alone sub-modules
