@@ -837,15 +837,14 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
             } else {
                 // only rows that HAVE a diagonal bit can change the outcome; visit those in order
                 const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-                unsigned long long cand = __ballot(d != 0ull);
+                unsigned long long cand = __ballot(d != 0ull) & ~rem;     // removed rows cannot act: dropped from the walk as it goes
                 while (cand) {
                     const int t = __builtin_ctzll(cand);
+                    const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                    const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                    rem |= ((unsigned long long)wh << 32) | wl;
                     cand &= cand - 1ull;
-                    if (!((rem >> t) & 1ull)) {
-                        const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
-                        const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
-                        rem |= ((unsigned long long)wh << 32) | wl;
-                    }
+                    cand &= ~rem;
                 }
                 kept = rowmask & ~rem;
             }
@@ -997,16 +996,18 @@ __device__ __forceinline__ int scan_team(const unsigned long long* __restrict__ 
                 asm volatile("" ::: "memory");
                 rv = removed[rb + 1 <= rb1 ? rb + 1 : rb1];
             }
-            unsigned long long cand = __ballot(d != 0ull);
+            // only rows with a diagonal bit can change the outcome, and only while they are not removed themselves: dropping
+            // the removed rows from the walk after every step makes its length the number of KEPT rows with a diagonal bit
+            // (clustered boxes: all 64 rows have one, two or three survive - the walk was most of the scan there)
+            unsigned long long cand = __ballot(d != 0ull) & ~rem;
             const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-            while (cand) {                              // only rows with a diagonal bit can change the outcome
+            while (cand) {
                 const int t = __builtin_ctzll(cand);
+                const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                rem |= ((unsigned long long)wh << 32) | wl;
                 cand &= cand - 1ull;
-                if (!((rem >> t) & 1ull)) {
-                    const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
-                    const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
-                    rem |= ((unsigned long long)wh << 32) | wl;
-                }
+                cand &= ~rem;
             }
             const unsigned long long kept = rowmask & ~rem;
             const unsigned long long work = kept & any_rb;
@@ -1172,16 +1173,18 @@ __global__ __launch_bounds__(1024) void nms_scan_classes_kernel(const unsigned l
             const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem_v);
             const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem_v >> 32));
             unsigned long long rem = ((unsigned long long)rem_hi << 32) | rem_lo;
-            unsigned long long cand = __ballot(d != 0ull);
+            // only rows with a diagonal bit can change the outcome, and only while they are not removed themselves: dropping
+            // the removed rows from the walk after every step makes its length the number of KEPT rows with a diagonal bit
+            // (clustered boxes: all 64 rows have one, two or three survive - the walk was most of the scan there)
+            unsigned long long cand = __ballot(d != 0ull) & ~rem;
             const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-            while (cand) {                              // only rows with a diagonal bit can change the outcome
+            while (cand) {
                 const int t = __builtin_ctzll(cand);
+                const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
+                const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
+                rem |= ((unsigned long long)wh << 32) | wl;
                 cand &= cand - 1ull;
-                if (!((rem >> t) & 1ull)) {
-                    const unsigned wl = __builtin_amdgcn_readlane(dlo, t);
-                    const unsigned wh = __builtin_amdgcn_readlane(dhi, t);
-                    rem |= ((unsigned long long)wh << 32) | wl;
-                }
+                cand &= ~rem;
             }
             const unsigned long long kept = rowmask & ~rem;
             count += __popcll(kept);
