@@ -12,7 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 B, S, nc = 32, 416, 2
 dev = torch.device("cuda:0")
 m = yt.YOLOv3(num_classes=nc).to(dev).train()
-opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+opt = (torch.optim.SGD if os.environ.get("TORCH_SGD") else yt.SGD)(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
 anchors = gi.TRAIN_CASE["anchors"]
 sa = (torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)).to(dev)
 tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(B, S, nc, anchors, 3)]
