@@ -14,6 +14,7 @@ Data layout in HBM (fp32 path)
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -567,8 +568,9 @@ class ModelState:
                 preds = [t.to(hd) for t in preds]
         return preds
 
-    @staticmethod
-    def raise_on_nan(flag_tensor):
+    def raise_on_nan(self, flag_tensor):
+        # (a copy into pinned memory + a spinning event wait instead of .item() was tried against the 0.2 ms gap after an fp32
+        # forward: no difference, 1,677 vs 1,680 images/s)
         flag = int(flag_tensor.item())
         assert not (flag & 1), "NaN in the input tensor"          # model.py:175
         if flag & 2:

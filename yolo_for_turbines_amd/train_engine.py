@@ -489,10 +489,7 @@ def forward_train(state, model, x):
         holder = (state, model, plan, plist)
         preds = YoloTrainFn.apply(x, holder, *plist)
         if state.nan_check:
-            flag = int(plan.nan_flag.item())
-            assert not (flag & 1), "NaN in the input tensor"
-            if flag & 2:
-                raise ValueError("Nan in layer")
+            state.raise_on_nan(plan.nan_flag)
         hd = state.head_dtype()
         if hd != torch.float32:                       # what autocast hands the reference's loss (train.py:53-65); the cast is an
             preds = [t.to(hd) for t in preds]         # autograd op, so the incoming gradient is widened back to fp32
