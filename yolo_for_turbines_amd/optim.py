@@ -12,7 +12,11 @@ from . import _lib as L
 
 
 class SGD(torch.optim.SGD):
-    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, *, maximize=False):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, *, maximize=False,
+                 foreach=None, differentiable=False, fused=None):
+        # foreach / fused select among PyTorch's own implementations: accepted for signature compatibility, irrelevant here
+        if differentiable:
+            raise ValueError("yolo_for_turbines_amd.optim.SGD: differentiable=True is not supported")
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
                          maximize=maximize)
         self._tables = {}                                   # group index -> (params, chunk table, pinned items, device items)
