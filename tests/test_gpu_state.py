@@ -163,11 +163,12 @@ def test_second_train_forward_before_backward_is_refused(yt):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
-@pytest.mark.parametrize("ac", [False, True])
+@pytest.mark.parametrize("ac", [False, True, "fp16_scaler"])
 def test_training_with_the_fused_sgd_step_follows_torch_sgd(yt, ac):
     """Three fine-tune steps with yt.SGD (parameters written through raw pointers by one HIP launch) and three with
     torch.optim.SGD from the same start: every parameter and running statistic bit-equal after each step. Catches an update
-    the engine does not notice (it re-packs a weight when its version counter moves), not only the update arithmetic."""
+    the engine does not notice (it re-packs a weight when its version counter moves), not only the update arithmetic.
+    fp32, bf16 autocast, and fp16 autocast stepped through torch.amp.GradScaler as train.py:67-69 does."""
     sd, x, tg, sa = _case(311)
     lf = yt.FusedYOLOLoss()
 
@@ -176,14 +177,20 @@ def test_training_with_the_fused_sgd_step_follows_torch_sgd(yt, ac):
         m.load_state_dict({k: v.clone() for k, v in sd.items()})
         m = m.cuda().train()
         opt = opt_cls(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        scaler = torch.amp.GradScaler(init_scale=256.0) if ac == "fp16_scaler" else None     # train.py:39,67-69
         snaps = []
         for _ in range(3):
             opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            with torch.autocast("cuda", dtype=torch.float16 if scaler else torch.bfloat16, enabled=bool(ac)):
                 preds = m(x)
                 loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
-            loss.backward()
-            opt.step()
+            if scaler:
+                scaler.scale(loss).backward()
+                scaler.step(opt)                                   # unscale, inf check, optimizer.step()
+                scaler.update()
+            else:
+                loss.backward()
+                opt.step()
             snaps.append({k: v.detach().clone() for k, v in m.state_dict().items()})
         return snaps
 
