@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict
 constexpr int SCAN_NEAR = 3;
 
 // grid (1, B, W), MS_WAVES waves: wave w takes row block rb against column blocks rb + w, + MS_WAVES, ... while the class ranges overlap
-constexpr int MS_WAVES = 4;      // waves per workgroup = column-block stride (a 64-thread workgroup per (row block, stride) was dispatch-bound at 80 classes)
+constexpr int MS_WAVES = 4;      // waves per workgroup = column-block stride (a 64-thread workgroup per (row block, stride) was dispatch-bound at 80
+                                 // classes). Same-box A/B: 8 waves give 2 classes 540 -> 572 M boxes/s but 80 classes 1,590 -> 1,527 M; 2 waves 383 M / 1,564 M
 __global__ __launch_bounds__(64 * MS_WAVES) void nms_mask_sorted_kernel(const SBox* __restrict__ sbox, const int* __restrict__ nvalid,
                                                              const int* __restrict__ blk_lo, const int* __restrict__ blk_hi, int n,
                                                              int W, float thr, unsigned long long* __restrict__ mask,
@@ -681,10 +682,14 @@ __global__ __launch_bounds__(64 * MS_WAVES) void nms_mask_sorted_kernel(const SB
     const SBox* sb = sbox + (size_t)b * n;
     const int i = rb * 64 + lane;
     const bool active = i < nv;
-    const SBox me = sb[active ? i : nv - 1];
     const int hi_r = blk_hi[(size_t)b * W + rb];
+    const int cb_first = rb + blockIdx.x * MS_WAVES + wave;
+    // a wave whose first column block is already outside the row block's class range has nothing to do (with 80 classes
+    // most of a workgroup's waves): it leaves before it asks for its rows' boxes
+    if (cb_first >= nblk || blk_lo[(size_t)b * W + cb_first] > hi_r) return;
+    const SBox me = sb[active ? i : nv - 1];
     const RowBounds rbnd = row_bounds(me, thr);
-    for (int cb = rb + blockIdx.x * MS_WAVES + wave; cb < nblk; cb += gridDim.x * MS_WAVES) {
+    for (int cb = cb_first; cb < nblk; cb += gridDim.x * MS_WAVES) {
         if (blk_lo[(size_t)b * W + cb] > hi_r) break;    // classes ascend: no later block can match either
         const int j = cb * 64 + lane;
         __builtin_amdgcn_wave_barrier();
