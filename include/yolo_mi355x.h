@@ -224,6 +224,12 @@ typedef struct yolo_sgd_item { float* p; const float* g; float* buf; long long n
 int yolo_sgd_chunk_elems(void);
 int yolo_sgd_step(const void* items_dev, const int32_t* chunks_dev, int n_chunks, float lr, float momentum, float dampening,
                   float weight_decay, int nesterov, int maximize, void* stream);
+/* The same update with {lr, momentum, dampening, weight_decay} read from DEVICE memory (16-byte aligned float[4]) when the
+ * kernel runs: a launch captured in a HIP graph then follows the LR scheduler of train.py:71-74,187-189 (stepped after
+ * every batch) instead of replaying the capture-time values. nesterov needs momentum > 0 and dampening == 0 (caller's
+ * responsibility here: the values are not on the host). */
+int yolo_sgd_step_hp(const void* items_dev, const int32_t* chunks_dev, int n_chunks, const float* hyper4_dev, int nesterov, int maximize,
+                     void* stream);
 
 /* ---- post-processing ------------------------------------------------------------------- */
 /* Replaces cells_to_boxes (utils.py:86-148) for one scale.

@@ -443,8 +443,135 @@ def gen_checkpoint():
     np.savez_compressed(os.path.join(OUT, "checkpoint.npz"), **out)
 
 
+# ------------------------------------------------- multi-step trajectory (train.py:41-82, several iterations)
+TRAJ_STEPS, TRAJ_OPT, TRAJ_SCHED, TRAJ_WEIGHT_KEYS = gi.TRAJ_STEPS, gi.TRAJ_OPT, gi.TRAJ_SCHED, gi.TRAJ_WEIGHT_KEYS
+
+
+def gen_train_traj():
+    """THREE consecutive iterations of the reference's loop body (train.py:41-82: zero_grad, forward, three per-scale losses,
+    backward, optimizer.step, scheduler.step) on one seeded batch, run by the imported reference in fp32: steps 2+ exercise
+    what a single step cannot - momentum buffers, running-statistic accumulation, num_batches_tracked, the LR schedule and
+    re-packing after optimizer.step()."""
+    c = gi.TRAIN_CASE
+    out = {}
+    for tag, act in (("leaky", "leaky_relu"), ("mish", "mish")):
+        sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+        m = ref_net(c["nc"], act, sd).train()
+        x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+        tg = [torch.from_numpy(t) for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+        grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+        sa = torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)
+        lf = ref_loss.YOLOLoss()
+        opt = torch.optim.SGD(m.parameters(), **TRAJ_OPT)
+        sched = torch.optim.lr_scheduler.LinearLR(opt, **TRAJ_SCHED)
+        parts_all, lrs = [], []
+        for step in range(TRAJ_STEPS):
+            opt.zero_grad()
+            preds = m(x)
+            parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+            parts.sum().backward()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+            parts_all.append(parts.detach().numpy())
+        out[f"{tag}/loss_parts"] = np.stack(parts_all)                       # (steps, 3 scales, 4 parts)
+        out[f"{tag}/lrs"] = np.array(lrs, np.float64)
+        out[f"{tag}/gradnorm_step3"] = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+        st = m.state_dict()
+        out[f"{tag}/rm0"] = st["layers.0.batch_norm.running_mean"].numpy().copy()
+        out[f"{tag}/rv0"] = st["layers.0.batch_norm.running_var"].numpy().copy()
+        out[f"{tag}/nbt0"] = np.array(int(st["layers.0.batch_norm.num_batches_tracked"]))
+        out[f"{tag}/rv_last"] = st["layers.28.batch_norm.running_var"].numpy().copy()
+        for k in TRAJ_WEIGHT_KEYS:
+            out[f"{tag}/w/{k}"] = st[k].reshape(-1)[::7].numpy().copy()
+            out[f"{tag}/wsums/{k}"] = sums(st[k])
+        out[f"{tag}/param_norms"] = np.array([float(p.detach().double().norm()) for p in m.parameters()])
+        out[f"{tag}/momentum_norms"] = np.array([float(opt.state[p]["momentum_buffer"].double().norm()) for p in m.parameters()])
+        print("traj", tag, [float(p.sum()) for p in parts_all], lrs)
+    np.savez_compressed(os.path.join(OUT, "train_traj.npz"), **out)
+
+
+# ---------------------------------- the reference's UNCHANGED loader on this package's module (SURVEY §8a row 7)
+def gen_loader_bind():
+    """SURVEY §8a row 7 asks that the reference's loader (`model.py:227-337`) drops in unchanged. Here its four functions -
+    the very code objects of the imported reference, with only the three class names its isinstance tests look up
+    (CNNBlock / ResidualBlock / ScalePredictionBlock) resolving to this package's classes, i.e. what `from model import`
+    becoming `from yolo_for_turbines_amd import` does - are run on a CPU-constructed `yolo_for_turbines_amd.YOLOv3`, and
+    every parameter and buffer is compared with (a) the reference model filled by its own loader and (b) this package's
+    restated loader. Full file, the `.conv.74` cutoff, and freeze=True."""
+    import types
+    import yolo_for_turbines_amd as yt
+    out = {}
+    names = ("load_weights", "load_CNNBlock", "load_block_weights", "load_layer_weights")
+    glb = dict(ref_model.__dict__)
+    glb.update(CNNBlock=yt.CNNBlock, ResidualBlock=yt.ResidualBlock, ScalePredictionBlock=yt.ScalePredictionBlock)
+    bound = {n: types.FunctionType(getattr(ref_model.YOLOv3, n).__code__, glb, n) for n in names}
+    sd = onet.synth_state_dict(21, 3, 80, gain=1.0)
+    stream = onet.darknet_stream(sd, 3, 80)
+    with tempfile.TemporaryDirectory() as td:
+        for fname, freeze in (("yolov3.weights", False), ("darknet53.conv.74", True)):
+            path = os.path.join(td, fname)
+            with open(path, "wb") as f:
+                np.array([0, 2, 0, 32013312, 0], np.int32).tofile(f)
+                stream.tofile(f)
+            torch.manual_seed(5)
+            ref = ref_model.YOLOv3(num_classes=80, weights_path=path, freeze=freeze)
+            init = {k: v.clone() for k, v in ref.state_dict().items()}
+            ref.load_weights()
+            mine_bound = yt.YOLOv3(num_classes=80, weights_path=path, freeze=freeze)
+            mine_bound.load_state_dict(init)                    # same starting point for the tensors the cutoff leaves alone
+            for n in names:                                      # instance attributes shadow the package's own methods
+                setattr(mine_bound, n, types.MethodType(bound[n], mine_bound))
+            mine_bound.load_weights()
+            mine_own = yt.YOLOv3(num_classes=80, weights_path=path, freeze=freeze)
+            mine_own.load_state_dict(init)
+            mine_own.load_weights()
+            a, b, c = ref.state_dict(), mine_bound.state_dict(), mine_own.state_dict()
+            assert list(a) == list(b) == list(c)
+            for k in a:
+                assert torch.equal(a[k], b[k]), ("bound", fname, k)
+                assert torch.equal(a[k], c[k]), ("restated", fname, k)
+            ra = {k: p.requires_grad for k, p in ref.named_parameters()}
+            rb = {k: p.requires_grad for k, p in mine_bound.named_parameters()}
+            rc = {k: p.requires_grad for k, p in mine_own.named_parameters()}
+            assert ra == rb == rc, fname
+            assert (ref.param_idx, ref.layer_id) == (mine_bound.param_idx, mine_bound.layer_id) == (mine_own.param_idx, mine_own.layer_id)
+            tag = "full" if fname == "yolov3.weights" else "conv74_freeze"
+            out[f"{tag}/keys"] = np.array(list(a))
+            out[f"{tag}/sums"] = np.array([float(v.double().sum()) for v in a.values()])
+            out[f"{tag}/abs_sums"] = np.array([float(v.double().abs().sum()) for v in a.values()])
+            out[f"{tag}/init_sums"] = np.array([float(v.double().sum()) for v in init.values()])
+            out[f"{tag}/requires_grad"] = np.array([ra[k] for k, _ in ref.named_parameters()], bool)
+            out[f"{tag}/counters"] = np.array([ref.param_idx, ref.layer_id], np.int64)
+            out[f"{tag}/bound_equal"] = np.array(1)
+            out[f"{tag}/restated_equal"] = np.array(1)
+            print("loader_bind", fname, "frozen:", int(np.sum(~out[f'{tag}/requires_grad'])), "counters", ref.param_idx, ref.layer_id)
+    np.savez_compressed(os.path.join(OUT, "loader_bind.npz"), **out)
+
+
+# ----------------------------------------------------------------------- in_channels != 3 (model.py:151)
+NET_IN1 = gi.NET_IN1
+
+
+def gen_net_in1():
+    """Whole-network eval forward of the reference built with in_channels=1 (greyscale input): the first block is then
+    not the 3-channel stem the kernels special-case."""
+    c = NET_IN1
+    sd = onet.synth_state_dict(c["wseed"], c["in_channels"], c["nc"], gain=gi.NET_GAIN)
+    m = ref_model.YOLOv3(in_channels=c["in_channels"], num_classes=c["nc"], activation=c["act"])
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"], c["in_channels"])
+    with torch.no_grad():
+        preds = m(x)
+    out = {f"p{i}": p.contiguous().numpy() for i, p in enumerate(preds)}
+    np.savez_compressed(os.path.join(OUT, "net_in1.npz"), **out)
+    print("net_in1", [tuple(p.shape) for p in preds])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "train_fp64", "kat", "targets", "checkpoint"]
+    which = sys.argv[1:] or ["net", "blocks", "loader", "decode", "nms", "train", "train_fp64", "kat", "targets", "checkpoint", "train_traj", "loader_bind",
+                             "net_in1"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

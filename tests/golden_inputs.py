@@ -178,6 +178,14 @@ TRAIN_CASE = dict(nc=2, size=96, batch=4, wseed=11, xseed=12, tseed=13, act="lea
                            [(0.06, 0.143), (0.143, 0.189), (0.408, 0.181)],
                            [(0.016, 0.0349), (0.0408, 0.0598), (0.110, 0.0777)]])
 
+# multi-step trajectory on TRAIN_CASE (gen_golden.py train_traj): the reference's loop body, TRAJ_STEPS iterations
+TRAJ_STEPS = 3
+TRAJ_OPT = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4)
+TRAJ_SCHED = dict(start_factor=0.1, total_iters=8)       # train.py:187-189: LinearLR warm-up, stepped after every batch
+TRAJ_WEIGHT_KEYS = ("layers.0.conv.weight", "layers.29.pred_block.1.conv.weight")
+# whole network with in_channels = 1 (gen_golden.py net_in1)
+NET_IN1 = dict(nc=2, size=96, batch=2, act="leaky_relu", wseed=41, xseed=42, in_channels=1)
+
 
 def synth_targets(batch, size, nc, anchors, seed, mean_boxes=7):
     """COCO-shaped synthetic targets in the dataset's tensor format

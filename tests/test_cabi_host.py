@@ -91,6 +91,22 @@ def test_darknet_loader_offsets_and_cutoff(tmp_path, golden, fname, tag):
         else:
             assert torch.equal(after[key], before[key]), key
     assert m.param_idx == 62001757
+    # ... and against what the reference's UNCHANGED loader functions (model.py:227-337) left in a
+    # yolo_for_turbines_amd.YOLOv3 when gen_golden.py `loader_bind` ran them on it (same stream, same starting state):
+    # per-tensor sums, requires_grad flags (freeze), and the loader's counters
+    gb = golden("loader_bind")
+    bt = "full" if tag == "full" else "conv74_freeze"
+    assert int(gb[f"{bt}/bound_equal"]) == 1 and int(gb[f"{bt}/restated_equal"]) == 1
+    assert [str(k) for k in gb[f"{bt}/keys"]] == list(after)
+    for key, s_loaded, a_loaded, s_init in zip(after, gb[f"{bt}/sums"], gb[f"{bt}/abs_sums"], gb[f"{bt}/init_sums"]):
+        t = after[key].double()
+        if not torch.equal(after[key], before[key]):         # a loaded tensor: the values of the stream
+            assert abs(float(t.sum()) - s_loaded) <= 1e-9 * max(1.0, a_loaded), key
+            assert abs(float(t.abs().sum()) - a_loaded) <= 1e-9 * max(1.0, a_loaded), key
+        else:                                                # left alone by the cutoff - and the reference left it alone too
+            assert s_loaded == s_init or key.endswith("num_batches_tracked"), key
+    assert [p.requires_grad for p in m.parameters()] == [bool(v) for v in gb[f"{bt}/requires_grad"]]
+    assert (m.param_idx, m.layer_id) == tuple(int(v) for v in gb[f"{bt}/counters"])
     if tag == "conv74":
         named = dict(m.named_parameters())
         assert not named["layers.0.conv.weight"].requires_grad

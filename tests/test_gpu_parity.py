@@ -502,6 +502,86 @@ def test_network_train_step_vs_golden(yt, golden, tag, act):
     assert all(torch.isfinite(t).all() for t in a)
 
 
+@pytest.mark.parametrize("tag,act", [("leaky", "leaky_relu"), ("mish", "mish")])
+@pytest.mark.parametrize("opt_kind", ["yt", "torch"])
+def test_network_train_trajectory_vs_golden(yt, golden, tag, act, opt_kind):
+    """THREE iterations of the reference's loop body (train.py:41-82: zero_grad, forward, 3 x YOLOLoss, backward,
+    optimizer.step, LinearLR.step) against the trajectory the imported reference walked (tests/golden/train_traj.npz):
+    loss parts of every step (step 2+ see weights re-packed after optimizer.step, momentum, weight decay, the moving
+    learning rate), gradient norms of all 366 parameters at step 3, accumulated running statistics,
+    num_batches_tracked, parameter / momentum-buffer norms and two sampled weight tensors after step 3."""
+    g = golden("train_traj")
+    c = gi.TRAIN_CASE
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(num_classes=c["nc"], activation=act)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"]).cuda()
+    tg = [torch.from_numpy(t).cuda() for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    sa = (torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)).cuda()
+    lf = yt.YOLOLoss()
+    opt = (yt.SGD if opt_kind == "yt" else torch.optim.SGD)(m.parameters(), **gi.TRAJ_OPT)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, **gi.TRAJ_SCHED)
+    smooth = act == "mish"                       # LeakyReLU: a few |u| ~ 1e-6 elements take the other branch in any two fp32 runs
+    for step in range(gi.TRAJ_STEPS):
+        opt.zero_grad()
+        preds = m(x)
+        parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+        np.testing.assert_allclose(parts.detach().cpu().numpy(), g[f"{tag}/loss_parts"][step], rtol=1e-3 if smooth else 3e-3, atol=2e-5)
+        parts.sum().backward()
+        assert abs(opt.param_groups[0]["lr"] - g[f"{tag}/lrs"][step]) < 1e-12
+        opt.step()
+        sched.step()
+    norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    ref = g[f"{tag}/gradnorm_step3"]
+    np.testing.assert_allclose(norms, ref, rtol=5e-3 if smooth else 2e-2, atol=1e-6 * float(ref.max()))
+    st = m.state_dict()
+    np.testing.assert_allclose(st["layers.0.batch_norm.running_mean"].cpu().numpy(), g[f"{tag}/rm0"], atol=1e-5)
+    np.testing.assert_allclose(st["layers.0.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv0"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st["layers.28.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv_last"], rtol=5e-3, atol=1e-5)
+    assert int(st["layers.0.batch_norm.num_batches_tracked"]) == int(g[f"{tag}/nbt0"]) == gi.TRAJ_STEPS
+    pn = np.array([float(p.detach().double().norm()) for p in m.parameters()])
+    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=2e-5)
+    mn = np.array([float(opt.state[p]["momentum_buffer"].double().norm()) for p in m.parameters()])
+    refm = g[f"{tag}/momentum_norms"]
+    np.testing.assert_allclose(mn, refm, rtol=5e-3 if smooth else 2e-2, atol=1e-6 * float(refm.max()))
+    for k in gi.TRAJ_WEIGHT_KEYS:
+        want = g[f"{tag}/w/{k}"]
+        got = st[k].reshape(-1)[::7].cpu().numpy()
+        # the weights moved by sum(lr_t * update_t) ~ 6e-3 * |g|: compare the MOVEMENT, not the (much larger) weights
+        w0 = sd[k].reshape(-1)[::7].numpy()
+        moved = float(np.abs(want - w0).max())
+        assert moved > 0
+        assert float(np.abs(got - want).max()) <= (2e-3 if smooth else 5e-2) * moved + 1e-7, k
+
+
+def test_network_forward_in_channels_1_vs_golden(yt, golden):
+    """A network built with in_channels=1 (model.py:151): no 3-channel stem kernel applies, the first block goes through
+    the NHWC boundary copy and the generic convolution kernels. fp32 against the reference's outputs, 16-bit against the
+    same numbers at the 16-bit network tolerance."""
+    g = golden("net_in1")
+    c = gi.NET_IN1
+    sd = onet.synth_state_dict(c["wseed"], c["in_channels"], c["nc"], gain=gi.NET_GAIN)
+    m = yt.YOLOv3(in_channels=c["in_channels"], num_classes=c["nc"], activation=c["act"])
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"], c["in_channels"]).cuda()
+    with torch.no_grad():
+        preds = m(x)
+    for i, p in enumerate(preds):
+        ref = g[f"p{i}"]
+        assert tuple(p.shape) == ref.shape
+        np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    with pytest.raises(ValueError, match="input must be"):
+        m(torch.zeros(2, 3, 96, 96, device="cuda"))
+    m.train()                                     # and one fine-tune step runs (gradients finite, first-layer dW has 1 input channel)
+    po = m(x)
+    sum(p.float().square().mean() for p in po).backward()
+    assert m.layers[0].conv.weight.grad.shape == (32, 1, 3, 3)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
 def test_network_train_step_leaky_vs_fp64_on_matched_branches(yt, golden):
     """The LeakyReLU fine-tune step against FLOAT64, elementwise, every parameter.
 

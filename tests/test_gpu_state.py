@@ -199,3 +199,96 @@ def test_training_with_the_fused_sgd_step_follows_torch_sgd(yt, ac):
         for k in a[step]:
             assert torch.equal(a[step][k], b[step][k]), (step, k)
     assert not torch.equal(a[2]["layers.0.conv.weight"], a[0]["layers.0.conv.weight"])
+
+
+@pytest.mark.parametrize("ac", [None, torch.bfloat16])
+def test_graph_replays_follow_a_per_step_lr_schedule(yt, ac):
+    """The reference steps a LinearLR warm-up after EVERY batch (train.py:71-74,187-189). A replayed graph must train at
+    the scheduler's current learning rate, not at the capture-time one: yt.SGD reads its hyper-parameters from device
+    memory when the kernel runs. Replays under LinearLR == eager steps under LinearLR, bit for bit; and an optimizer that
+    bakes its floats into the capture (torch.optim.SGD) makes the replay raise once the LR has moved."""
+    sd, x, tg, sa = _case(351)
+    lf = yt.FusedYOLOLoss()
+
+    def make(opt_cls):
+        m = yt.YOLOv3(num_classes=NC, activation="mish")
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        m = m.cuda().train()
+        opt = opt_cls(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+        sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, total_iters=8)       # train.py:187-189
+        return m, opt, sched
+
+    def eager(m, opt):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=ac or torch.bfloat16, enabled=ac is not None):
+            po = m(x)
+            loss = sum(sum(lf(po[i], tg[i], sa[i])) for i in range(3))
+        loss.backward()
+        opt.step()
+
+    m1, o1, s1 = make(yt.SGD)
+    m2, o2, s2 = make(yt.SGD)
+    step = yt.GraphedTrainStep(m2, o2, sa, x, tg, autocast_dtype=ac, warmup=3)   # 3 warm-up steps at the initial LR
+    for _ in range(3):
+        eager(m1, o1)
+    lrs = []
+    for _ in range(4):
+        s1.step()
+        s2.step()
+        lrs.append(o2.param_groups[0]["lr"])
+        eager(m1, o1)
+        step(x, tg)
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            assert torch.equal(a, b), (k, lrs)
+    assert len(set(lrs)) == 4                                       # the schedule really moved between replays
+    # momentum / weight decay changed by hand between replays are picked up as well
+    for o in (o1, o2):
+        o.param_groups[0]["momentum"] = 0.5
+        o.param_groups[0]["weight_decay"] = 1e-3
+    eager(m1, o1)
+    step(x, tg)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # torch.optim.SGD captures Python floats: refuse to replay at a stale learning rate
+    m3, o3, s3 = make(torch.optim.SGD)
+    step3 = yt.GraphedTrainStep(m3, o3, sa, x, tg, autocast_dtype=ac)
+    step3(x, tg)
+    s3.step()
+    with pytest.raises(RuntimeError, match="hyper-parameters changed since the capture"):
+        step3(x, tg)
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_head_bias_changed_alone_is_seen_by_the_next_train_forward(yt, autocast):
+    """The heads have no BatchNorm: in training too the kernel gets (scale, shift) = (1, conv bias) from the folded cache.
+    A bias that changes on its own (objectness-prior init after a first forward, frozen weights with a trainable bias, a
+    partial load_state_dict) must reach the next train-mode forward although no conv weight moved."""
+    sd, x, tg, sa = _case(361)
+    m = yt.YOLOv3(num_classes=NC, activation="leaky_relu")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+
+    def fwd():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            return [p.detach().float().clone() for p in m(x)]
+    a = fwd()
+    heads = [m.layers[i].pred_block[1].conv for i in (15, 22, 29)]
+    with torch.no_grad():
+        for h in heads:
+            h.bias.add_(1.0)
+    b = fwd()
+    for p, q in zip(a, b):
+        d = q - p
+        assert float((d - 1.0).abs().max()) < (2e-2 if autocast else 1e-5)
+    # replacing the Parameter OBJECT (same values elsewhere in memory) is seen too, in eval (fast walk) and in training
+    m.eval()
+    with torch.no_grad():
+        e0 = [p.clone() for p in m(x)]
+        e0b = [p.clone() for p in m(x)]                              # second call: the fast freshness walk is armed
+    for p, q in zip(e0, e0b):
+        assert torch.equal(p, q)
+    heads[0].bias = torch.nn.Parameter(heads[0].bias.detach().clone() - 1.0)
+    with torch.no_grad():
+        e1 = m(x)
+    assert float((e1[0] - e0[0] + 1.0).abs().max()) < 1e-5
+    assert torch.equal(e1[1], e0[1])

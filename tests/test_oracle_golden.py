@@ -202,6 +202,64 @@ def test_train_step_losses_and_grads(golden):
     np.testing.assert_allclose(stats["layers.0.batch_norm.running_mean"].numpy(), g["leaky/rm0"], atol=1e-6)
 
 
+@pytest.mark.parametrize("tag,act", [("leaky", "leaky_relu"), ("mish", "mish")])
+def test_train_trajectory_three_steps(golden, tag, act):
+    """Three iterations of the reference's loop body (train.py:41-82) on the oracle: momentum buffers, weight decay, the
+    per-batch LinearLR warm-up, running-statistic accumulation and num_batches_tracked, against the imported reference's
+    trajectory (tests/golden/train_traj.npz)."""
+    from oracle import loss as oloss
+    g = golden("train_traj")
+    c = gi.TRAIN_CASE
+    sd = onet.synth_state_dict(c["wseed"], 3, c["nc"], gain=gi.NET_GAIN)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd)
+    full.update(params)
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"])
+    tg = [torch.from_numpy(t) for t in gi.synth_targets(c["batch"], c["size"], c["nc"], c["anchors"], c["tseed"])]
+    grids = [c["size"] // 32, c["size"] // 16, c["size"] // 8]
+    sa = torch.tensor(c["anchors"]) * torch.tensor(grids).view(3, 1, 1)
+    order = [k for k, _ in onet.state_dict_spec(3, c["nc"]) if k in params]     # = model.parameters() order
+    opt = torch.optim.SGD([params[k] for k in order], **gi.TRAJ_OPT)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, **gi.TRAJ_SCHED)
+    nbt = 0
+    for step in range(gi.TRAJ_STEPS):
+        opt.zero_grad()
+        stats = {}
+        preds = onet.forward(full, x, c["nc"], act, training=True, new_stats=stats)
+        parts = torch.stack([torch.stack(oloss.yolo_loss(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
+        np.testing.assert_allclose(parts.detach().numpy(), g[f"{tag}/loss_parts"][step], rtol=5e-4, atol=1e-5)
+        parts.sum().backward()
+        assert abs(opt.param_groups[0]["lr"] - g[f"{tag}/lrs"][step]) < 1e-12
+        opt.step()
+        sched.step()
+        full.update(stats)                                 # running statistics carry over to the next iteration
+        nbt += 1
+    norms = np.array([float(params[k].grad.double().norm()) for k in order])
+    np.testing.assert_allclose(norms, g[f"{tag}/gradnorm_step3"], rtol=2e-3, atol=1e-6 * float(norms.max()))
+    np.testing.assert_allclose(full["layers.0.batch_norm.running_mean"].numpy(), g[f"{tag}/rm0"], atol=1e-6)
+    np.testing.assert_allclose(full["layers.0.batch_norm.running_var"].numpy(), g[f"{tag}/rv0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(full["layers.28.batch_norm.running_var"].numpy(), g[f"{tag}/rv_last"], rtol=1e-3, atol=1e-6)
+    assert nbt == int(g[f"{tag}/nbt0"])
+    for k in gi.TRAJ_WEIGHT_KEYS:
+        np.testing.assert_allclose(params[k].detach().reshape(-1)[::7].numpy(), g[f"{tag}/w/{k}"], rtol=0, atol=2e-6)
+    pn = np.array([float(params[k].detach().double().norm()) for k in order])
+    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=1e-5)
+    mn = np.array([float(opt.state[params[k]]["momentum_buffer"].double().norm()) for k in order])
+    np.testing.assert_allclose(mn, g[f"{tag}/momentum_norms"], rtol=2e-3, atol=1e-6 * float(mn.max()))
+
+
+def test_net_forward_in_channels_1(golden):
+    """in_channels = 1 (model.py:151): the oracle against the reference built with a one-channel input."""
+    g = golden("net_in1")
+    c = gi.NET_IN1
+    sd = onet.synth_state_dict(c["wseed"], c["in_channels"], c["nc"], gain=gi.NET_GAIN)
+    x = onet.synth_input(c["xseed"], c["batch"], c["size"], c["in_channels"])
+    with torch.no_grad():
+        preds = onet.forward(sd, x, c["nc"], c["act"])
+    for i, p in enumerate(preds):
+        np.testing.assert_allclose(p.contiguous().numpy(), g[f"p{i}"], rtol=0, atol=2e-5)
+
+
 # ------------------------------------------------------------------ target builder (dataset.py:119-161)
 @pytest.mark.parametrize("case", list(gi.TARGET_CASES))
 def test_targets_oracle_equals_reference_getitem(golden, case):

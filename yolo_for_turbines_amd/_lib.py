@@ -52,6 +52,7 @@ _SIGS = {
                                     C.c_int, C.c_void_p]),
     "yolo_sgd_chunk_elems": (C.c_int, []),
     "yolo_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "yolo_sgd_step_hp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "yolo_stem_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "yolo_stem_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -1,6 +1,7 @@
 // Shared host-side helpers for libyolo_mi355x.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include "../../include/yolo_mi355x.h"
@@ -14,6 +15,23 @@ int fail(int code, const char* fmt, ...);
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(YOLO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return YOLO_OK;
+}
+
+// Kernels that need more than 64 KiB of dynamic LDS have to ask for it once per kernel AND per device (the attribute is
+// per device; plans are keyed by device index, so one process driving several GPUs is a supported case). One LdsOnce per
+// call site (i.e. per kernel instantiation); bit d = "device d has been configured".
+struct LdsOnce { std::atomic<unsigned long long> done{0}; };
+inline int reserve_lds(LdsOnce& st, const void* fn, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(YOLO_ERR_LAUNCH, "%s: no current device", what); }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (st.done.load(std::memory_order_relaxed) & bit) return YOLO_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(YOLO_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, bytes);
+    }
+    st.done.fetch_or(bit, std::memory_order_relaxed);
     return YOLO_OK;
 }
 

@@ -2038,15 +2038,8 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
     a.mtab_off = 2 * D_PATCH_BYTES + D_SLOTS * (BN / 32) * 2048;
     size_t lds = (size_t)a.mtab_off + 256 * sizeof(int) + 2 * BN * sizeof(float);
     if (g_h_dma_solo) lds = 100 * 1024;                     // experiment: ONE block per CU (how fast is a block that has the SIMDs to itself?)
-    static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_h16<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YOLO_ERR_LAUNCH, "conv3_dma_h16: cannot reserve %zu bytes of LDS", lds);
-        }
-        configured = true;
-    }
+    static LdsOnce once;                                    // per device (common.h)
+    if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&conv3_dma_h16<T, BN>), lds, "conv3_dma_h16")) return rc;
 #ifdef H16_PROBES
     // diagnostic library only (make probes): tile 9 = MFMA-shape probe, tiles 16 + bits = ablations of the K step (d_kstep)
     {
@@ -2076,14 +2069,8 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
         const int cap = g_h_dma_persist > 0 ? g_h_dma_persist : 2 * g_h_num_cus;
         const int grid = a.nblocks < cap ? a.nblocks : cap;
         auto go = [&](auto kern) {
-            static bool configured_p = false;               // one flag per instantiation of this generic lambda
-            if (!configured_p) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return fail(YOLO_ERR_LAUNCH, "conv3_dmap_h16: cannot reserve %zu bytes of LDS", lds_p);
-                }
-                configured_p = true;
-            }
+            static LdsOnce once_p;                          // one per instantiation of this generic lambda
+            if (int rc = reserve_lds(once_p, reinterpret_cast<const void*>(kern), lds_p, "conv3_dmap_h16")) return rc;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_p, s, a);
             return check_launch("conv3_dmap_h16");
         };
@@ -2104,15 +2091,8 @@ static int launch_dma1(ConvHArgs& a, hipStream_t s) {
     fill_magics(a);
     a.prio = g_h_prio ? 1 : 0;
     const size_t lds = (size_t)E_SLOTS * E_SLOT_BYTES;      // 80 KiB: two blocks per CU
-    static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_dma_h16<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YOLO_ERR_LAUNCH, "conv1_dma_h16: cannot reserve %zu bytes of LDS", lds);
-        }
-        configured = true;
-    }
+    static LdsOnce once;
+    if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&conv1_dma_h16<T, BN>), lds, "conv1_dma_h16")) return rc;
     hipLaunchKernelGGL((conv1_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv1_dma_h16");
 }

@@ -56,9 +56,17 @@ __device__ __forceinline__ void sgd_update(float* __restrict__ p, const float* _
     }
 }
 
-// chunks[c] = (item index, first element): built once per optimizer (sizes never change), the items every step
-__global__ __launch_bounds__(256) void sgd_step_kernel(const SgdItem* __restrict__ items, const int2* __restrict__ chunks, float neg_lr,
-                                                       float momentum, float omd, float wd, int nesterov, int maximize) {
+// chunks[c] = (item index, first element): built once per optimizer (sizes never change), the items every step.
+// hyper != nullptr: {lr, momentum, dampening, weight_decay} are read from device memory at EXECUTION time, so a captured
+// launch follows a learning-rate schedule (train.py:71-74 steps a LinearLR warm-up after every batch) instead of replaying
+// the values of the capture; the by-value arguments are then ignored.
+__global__ __launch_bounds__(256) void sgd_step_kernel(const SgdItem* __restrict__ items, const int2* __restrict__ chunks,
+                                                       const float* __restrict__ hyper, float neg_lr, float momentum, float omd, float wd,
+                                                       int nesterov, int maximize) {
+    if (hyper != nullptr) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(hyper);
+        neg_lr = -h[0]; momentum = h[1]; omd = 1.0f - h[2]; wd = h[3];
+    }
     const int2 ck = chunks[blockIdx.x];
     const SgdItem it = items[ck.x];
     if (it.g == nullptr) return;                         // parameter without a gradient this step: skipped, like PyTorch
@@ -89,8 +97,17 @@ int yolo_sgd_step(const void* items_dev, const int32_t* chunks_dev, int n_chunks
     if (!items_dev || !chunks_dev || n_chunks < 0) return fail(YOLO_ERR_ARG, "sgd_step: bad arguments");
     if (nesterov && (momentum <= 0.f || dampening != 0.f)) return fail(YOLO_ERR_ARG, "sgd_step: nesterov needs momentum > 0 and dampening = 0");
     hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const SgdItem*)items_dev,
-                       (const int2*)chunks_dev, -lr, momentum, 1.0f - dampening, weight_decay, nesterov, maximize);
+                       (const int2*)chunks_dev, (const float*)nullptr, -lr, momentum, 1.0f - dampening, weight_decay, nesterov, maximize);
     return check_launch("sgd_step");
+}
+
+int yolo_sgd_step_hp(const void* items_dev, const int32_t* chunks_dev, int n_chunks, const float* hyper4_dev, int nesterov, int maximize,
+                     void* stream) {
+    if (n_chunks == 0) return YOLO_OK;
+    if (!items_dev || !chunks_dev || !hyper4_dev || n_chunks < 0 || ((size_t)hyper4_dev & 15)) return fail(YOLO_ERR_ARG, "sgd_step_hp: bad arguments");
+    hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const SgdItem*)items_dev,
+                       (const int2*)chunks_dev, hyper4_dev, 0.f, 0.f, 1.f, 0.f, nesterov, maximize);
+    return check_launch("sgd_step_hp");
 }
 
 }  // extern "C"

@@ -300,15 +300,9 @@ static int launch_wh(const WgradHArgs& a, hipStream_t s) {
     constexpr int PC = STRIDE * 15 + KS, PR = STRIDE * (TH - 1) + KS;
     constexpr int ROW = 64 * TT * 2 + 64;
     const size_t lds = 2 * (size_t)(TH * 16 * ROW + PR * PC * ROW);
-    static bool configured = false;                         // > 64 KiB of dynamic LDS has to be requested once per kernel
-    if (!configured && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_patch_h16<T, KS, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YOLO_ERR_LAUNCH, "wgrad_patch_h16: cannot reserve %zu bytes of LDS", lds);
-        }
-        configured = true;
-    }
+    static LdsOnce once;
+    if (lds > 65536)
+        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&wgrad_patch_h16<T, KS, STRIDE>), lds, "wgrad_patch_h16")) return rc;
     hipLaunchKernelGGL((wgrad_patch_h16<T, KS, STRIDE>), dim3(a.ntile * a.nslices), dim3(256), lds, s, a);
     return check_launch("wgrad_patch_h16");
 }

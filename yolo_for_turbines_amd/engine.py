@@ -210,7 +210,8 @@ class PackedBlock:
         BatchNorm running statistics in a train-mode forward, every parameter in a HIP-graph replay) are covered by
         ``ModelState.mark_unfolded`` / ``invalidate`` instead."""
         w, rest = PackedBlock.stamp_tensors(block)
-        return ((w.data_ptr(), w._version),), tuple((t.data_ptr(), t._version) for t in rest)
+        gen = block.__dict__.get("_pack_gen", 0)       # CNNBlock.set_layers (the reference loader's hand-back) counts here
+        return ((w.data_ptr(), w._version, gen),), tuple((t.data_ptr(), t._version, gen) for t in rest)
 
     @staticmethod
     def stamp_tensors(block):
@@ -225,6 +226,17 @@ class PackedBlock:
             pr, bf = bn._parameters, bn._buffers
             return w, (pr["weight"], pr["bias"], bf["running_mean"], bf["running_var"])
         return w, (conv._parameters["bias"],)
+
+    @staticmethod
+    def stamp_slots(block):
+        """(owner dictionary, key) of every tensor `stamp_tensors` returns, for the fast freshness walk."""
+        mods = block._modules
+        conv = mods["conv"]
+        if block.batch_norm_act:
+            bn = mods["batch_norm"]
+            pr, bf = bn._parameters, bn._buffers
+            return ((conv._parameters, "weight"), (pr, "weight"), (pr, "bias"), (bf, "running_mean"), (bf, "running_var"))
+        return ((conv._parameters, "weight"), (conv._parameters, "bias"))
 
     def refresh(self, block, stream, fold_bn=True, conv_packed=False, pack=True):
         """fold_bn=False (training: batch statistics are used, not the running ones) skips the BN fold.
@@ -376,7 +388,7 @@ class ModelState:
         self._defer_nan = False           # detect_images(): the forward leaves its NaN flag for the caller to read
         self._pending_flag = None
         self._gen = 0                     # bumped whenever packed state is declared out of date by hand (invalidate, mark_unfolded)
-        self._fast = {}                   # (id(blocks), device, dtype, fold_bn) -> (gen, blocks, [(tensor, version, address)])
+        self._fast = {}                   # (id(blocks), device, dtype) -> (gen, blocks, [(owner dict, key, tensor, version, address)])
         self._plans = {}
         self.nan_check = True
         self.tile_override = None
@@ -450,28 +462,33 @@ class ModelState:
         return pk
 
     def refresh_weights(self, blocks, device, stream, dtype="fp32", fold_bn=True):
-        # fast path: nothing this library or PyTorch wrote since the last full check of this very list of blocks -
-        # one flat walk over (tensor, version, address) instead of rebuilding 75 pairs of stamps
-        fkey = (id(blocks), device.index, dtype, fold_bn)
+        # fast path (eval plans, whose block list lives as long as the plan): nothing this library or PyTorch wrote since
+        # the last full check of this very list of blocks - one flat walk over (owner dict, key, tensor, version, address)
+        # instead of rebuilding 75 pairs of stamps. The walk re-reads the modules' CURRENT entries: a replaced Parameter
+        # object (pruning, parametrize, `conv.weight = nn.Parameter(...)`) fails `is` and takes the slow path.
+        # Training (fold_bn=False) never uses it: after an optimizer step every weight is stale anyway, and
+        # `mark_unfolded` moves the generation on every train-mode forward.
+        if not fold_bn:
+            self._refresh_weights_slow(blocks, device, stream, dtype, fold_bn)
+            return
+        fkey = (id(blocks), device.index, dtype)
         fast = self._fast.get(fkey)
         if fast is not None and fast[0] == self._gen and fast[1] is blocks:
-            for t, ver, ptr in fast[2]:
-                if t._version != ver or t.data_ptr() != ptr:
+            for owner, name, t, ver, ptr in fast[2]:
+                if owner[name] is not t or t._version != ver or t.data_ptr() != ptr:
                     break
             else:
-                return
+                if all(blk.__dict__.get("_pack_gen", 0) == gen for blk, gen in fast[3]):
+                    return
         self._refresh_weights_slow(blocks, device, stream, dtype, fold_bn)
         flat = []
         for blk in blocks:
-            w, rest = PackedBlock.stamp_tensors(blk)
-            if blk.conv._parameters["weight"] is not w:
-                break
-            flat.append((w, w._version, w.data_ptr()))
-            flat.extend((t, t._version, t.data_ptr()) for t in rest)
-        else:
-            if len(self._fast) > 64:
-                self._fast.clear()
-            self._fast[fkey] = (self._gen, blocks, flat)
+            for owner, name in PackedBlock.stamp_slots(blk):
+                t = owner[name]
+                flat.append((owner, name, t, t._version, t.data_ptr()))
+        if len(self._fast) > 64:
+            self._fast.clear()
+        self._fast[fkey] = (self._gen, blocks, flat, [(blk, blk.__dict__.get("_pack_gen", 0)) for blk in blocks])
 
     def _refresh_weights_slow(self, blocks, device, stream, dtype="fp32", fold_bn=True):
         stale, refold = [], []
@@ -480,8 +497,11 @@ class ModelState:
             wst, fst = PackedBlock.stamp_of(blk)
             if pk.stamp is None or pk.stamp != wst:
                 stale.append((blk, pk))
-            elif fold_bn and (not pk.folded or pk.fold_stamp != fst):
-                refold.append((blk, pk))             # weights current, scale / shift not (e.g. frozen conv, live running stats)
+            elif (fold_bn or not blk.batch_norm_act) and (not pk.folded or pk.fold_stamp != fst):
+                # weights current, scale / shift not: a frozen conv with live running statistics (eval), or - in training
+                # too, where the heads have no BatchNorm and feed scale / shift = (1, conv bias) to the kernel - a head
+                # bias that changed on its own (prior-probability init after a first forward, partial load_state_dict)
+                refold.append((blk, pk))
         # 16-bit: all stale conv weights in one launch per 48 layers (after an optimizer step that is every layer)
         batched = set()
         if dtype != "fp32" and len(stale) > 1:

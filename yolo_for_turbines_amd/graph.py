@@ -56,6 +56,11 @@ class GraphedTrainStep:
             self._plan = plans[-1]
             self._plan.pinned = True
             self.graph = torch.cuda.CUDAGraph()
+            # Hyper-parameters across replays: `yt.SGD` keeps them in device memory and reads them when the kernel runs
+            # (`sync_hyper` before each replay), so LR schedulers keep working. Any other optimizer bakes its Python floats
+            # into the captured kernels: remember them and refuse a replay at different values rather than train silently
+            # at the capture-time learning rate.
+            self._baked = None if hasattr(self.opt, "sync_hyper") else self._hyper_snapshot()
             if self.zero_grad:
                 self.opt.zero_grad(set_to_none=True)
             with torch.cuda.graph(self.graph):
@@ -73,12 +78,23 @@ class GraphedTrainStep:
         self.opt.step()
         return loss.detach()
 
+    def _hyper_snapshot(self):
+        keys = ("lr", "momentum", "dampening", "weight_decay", "nesterov", "maximize", "betas", "eps")
+        return [tuple((k, g[k]) for k in keys if k in g and not isinstance(g[k], torch.Tensor)) for g in self.opt.param_groups]
+
     def __call__(self, x, targets):
         if tuple(x.shape) != tuple(self.x.shape):
             raise ValueError(f"this graph was captured for input shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
         if self._plan.dropped:
             raise RuntimeError("GraphedTrainStep: the model dropped its plans after this graph was captured (model.to(...) / "
                                ".float() / .half() move the parameters the graph points at): capture a new GraphedTrainStep")
+        if self._baked is None:
+            self.opt.sync_hyper()                       # stream-ordered in front of the replay; no-op when nothing changed
+        elif self._hyper_snapshot() != self._baked:
+            raise RuntimeError("GraphedTrainStep: the optimizer's hyper-parameters changed since the capture "
+                               f"({self._baked} -> {self._hyper_snapshot()}) and this optimizer bakes them into the captured "
+                               "kernels; use yolo_for_turbines_amd.SGD (reads them from device memory at every replay) or "
+                               "capture a new GraphedTrainStep")
         self.x.copy_(x, non_blocking=True)
         for dst, src in zip(self.targets, targets):
             dst.copy_(src, non_blocking=True)

@@ -46,8 +46,13 @@ class CNNBlock(nn.Module):
         self.batch_norm = nn.BatchNorm2d(out_channels) if batch_norm_act else None
         self.activation = _make_activation(activation) if batch_norm_act else None
         self.batch_norm_act = batch_norm_act
+        self._pack_gen = 0
 
     def set_layers(self, layers):                                 # model.py:74-78
+        # The reference's loader (model.py:238-250) fills the tensors through `.data.copy_` - which PyTorch's version
+        # counters do not see - and then hands the layers back through this method: count it, so that packed weights made
+        # before such a load are re-made (engine.PackedBlock.stamp_of includes this counter).
+        self._pack_gen += 1
         self.conv = layers[0]
         if self.batch_norm_act:
             self.batch_norm = layers[1]

@@ -34,12 +34,38 @@ class _GroupTable:
         # ever write; pinned memory cannot be allocated inside a capture, so eager steps keep two spares ready
         self.spares = []
         self.captured = []
+        # {lr, momentum, dampening, weight_decay} live in DEVICE memory and the kernel reads them when it runs: a step
+        # captured in a HIP graph then follows the LR scheduler (train.py:71-74 steps LinearLR after every batch) instead of
+        # replaying the capture-time values. Written stream-ordered, outside any capture, whenever the group's values change
+        # (SGD.sync_hyper); pinned staging ring guarded by events like the row tables.
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.hyper_host = None                              # the values last pushed
+        self.hyper_ring = [[torch.zeros(4, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
+        self.hyper_slot = 0
 
     def _pinned(self):
         return torch.zeros((len(self.params), 4), dtype=torch.int64).pin_memory()
 
     def matches(self, params):
         return len(self.params) == len(params) and all(a is b for a, b in zip(self.params, params))
+
+    def push_hyper(self, values):
+        """Enqueue {lr, momentum, dampening, weight_decay} -> device on the current stream if they changed."""
+        if values == self.hyper_host:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("yolo_for_turbines_amd.optim.SGD: the hyper-parameters changed inside a stream capture; call "
+                               "optimizer.sync_hyper() (GraphedTrainStep does) before the replay instead")
+        slot = self.hyper_ring[self.hyper_slot]
+        self.hyper_slot = (self.hyper_slot + 1) % len(self.hyper_ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        h = slot[0]
+        h[0], h[1], h[2], h[3] = values
+        self.hyper.copy_(h, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        self.hyper_host = values
 
     def host_buffer(self, capturing):
         """(pinned buffer to fill, ring slot or None)."""
@@ -74,6 +100,22 @@ class SGD(torch.optim.SGD):
             t = self._tables[gi] = _GroupTable(params)
         return t
 
+    @staticmethod
+    def _hyper_of(group):
+        mom, damp = float(group["momentum"]), float(group["dampening"])
+        if group["nesterov"] and (mom <= 0.0 or damp != 0.0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        return (float(group["lr"]), mom, damp, float(group["weight_decay"]))
+
+    def sync_hyper(self):
+        """Push every group's current {lr, momentum, dampening, weight_decay} to the device (stream-ordered, a no-op when
+        nothing changed). `step()` does this itself in eager mode; call it before replaying a HIP graph that captured
+        `step()` whenever an LR scheduler (train.py:71-74,187-189) or the user changed `param_groups` in between."""
+        for gi, group in enumerate(self.param_groups):
+            tab = self._tables.get(gi)
+            if tab is not None:
+                tab.push_hyper(self._hyper_of(group))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -88,6 +130,11 @@ class SGD(torch.optim.SGD):
             tab = self._table(gi, params)
             mom = float(group["momentum"])
             capturing = torch.cuda.is_current_stream_capturing()
+            hyper = self._hyper_of(group)
+            if capturing and tab.hyper_host is None:
+                raise RuntimeError("yolo_for_turbines_amd.optim.SGD: take one eager step before capturing")
+            if not capturing or hyper != tab.hyper_host:      # inside a capture an unchanged value needs no node at all
+                tab.push_hyper(hyper)
             host, slot = tab.host_buffer(capturing)
             rows = host.numpy()                              # [p, g, momentum buffer, n] per parameter (yolo_sgd_item)
             updated = []
@@ -122,7 +169,7 @@ class SGD(torch.optim.SGD):
             if slot is not None:
                 slot[1] = torch.cuda.Event()
                 slot[1].record()
-            L.check(lib.yolo_sgd_step(tab.items.data_ptr(), tab.chunks.data_ptr(), tab.chunks.shape[0], float(group["lr"]), mom,
-                                      float(group["dampening"]), float(group["weight_decay"]), int(bool(group["nesterov"])),
-                                      int(bool(group["maximize"])), L.current_stream()), "yolo_sgd_step")
+            L.check(lib.yolo_sgd_step_hp(tab.items.data_ptr(), tab.chunks.data_ptr(), tab.chunks.shape[0], tab.hyper.data_ptr(),
+                                         int(bool(group["nesterov"])), int(bool(group["maximize"])), L.current_stream()),
+                    "yolo_sgd_step_hp")
         return loss

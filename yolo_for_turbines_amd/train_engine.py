@@ -84,6 +84,7 @@ class TrainPlan:
         self.bn_ws = torch.empty(max_bn, dtype=torch.uint8, device=device)
         self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.blocks = [op["block"] for op in prog.ops]
         self.dgrad_w = {}                 # op index -> packed gradient-conv weights
         self.buckets = None               # dist.GradBuckets when data-parallel
         self.gen = 0                      # bumped by every train-mode forward: a backward must see the buffers of ITS forward
@@ -99,9 +100,8 @@ def _forward(state, model, plan: TrainPlan, x):
     prog, B, dev = plan.prog, plan.B, plan.device
     stream = L.current_stream()
     ones, zeros = _consts(dev)
-    blocks = [op["block"] for op in prog.ops]
     code = plan.code
-    state.refresh_weights(blocks, dev, stream, plan.dtype, fold_bn=False)
+    state.refresh_weights(plan.blocks, dev, stream, plan.dtype, fold_bn=False)
     plan.nan_flag.zero_()
     xin = x.detach()
     if xin.dtype != torch.float32 or not xin.is_contiguous():
