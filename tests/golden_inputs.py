@@ -183,6 +183,7 @@ TRAJ_STEPS = 3
 TRAJ_OPT = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4)
 TRAJ_SCHED = dict(start_factor=0.1, total_iters=8)       # train.py:187-189: LinearLR warm-up, stepped after every batch
 TRAJ_WEIGHT_KEYS = ("layers.0.conv.weight", "layers.29.pred_block.1.conv.weight")
+TRAJ_PERTURB = 1e-6        # relative input perturbation of the reference's own conditioning runs (train_traj.npz */perturbed_totals)
 # whole network with in_channels = 1 (gen_golden.py net_in1)
 NET_IN1 = dict(nc=2, size=96, batch=2, act="leaky_relu", wseed=41, xseed=42, in_channels=1)
 

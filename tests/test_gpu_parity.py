@@ -523,37 +523,50 @@ def test_network_train_trajectory_vs_golden(yt, golden, tag, act, opt_kind):
     lf = yt.YOLOLoss()
     opt = (yt.SGD if opt_kind == "yt" else torch.optim.SGD)(m.parameters(), **gi.TRAJ_OPT)
     sched = torch.optim.lr_scheduler.LinearLR(opt, **gi.TRAJ_SCHED)
-    smooth = act == "mish"                       # LeakyReLU: a few |u| ~ 1e-6 elements take the other branch in any two fp32 runs
+    # Conditioning (tests/golden/train_traj.npz */perturbed_totals = the REFERENCE's own code on inputs perturbed by 1e-6): with
+    # Mish the summed loss of every step moves by ~1e-5, so the trajectory is pinned elementwise. With LeakyReLU it moves by
+    # 0.9 % at step 2 and 5 % at step 3 (the deepest BatchNorm layers normalise over 36 values per channel at this size; a
+    # handful of |u| ~ 1e-6 elements on the other side of the kink re-route whole channels), so no fp32 implementation with a
+    # different accumulation order can follow the reference's run closer than that: steps 2+ are bounded by twice the
+    # reference's own spread, step 1 (same weights, no dynamics yet) stays elementwise.
+    smooth = act == "mish"
+    ref_tot = g[f"{tag}/loss_parts"].sum(axis=(1, 2))
+    spread = np.abs(g[f"{tag}/perturbed_totals"] - ref_tot[None]).max(axis=0)
     for step in range(gi.TRAJ_STEPS):
         opt.zero_grad()
         preds = m(x)
         parts = torch.stack([torch.stack(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3)])
-        np.testing.assert_allclose(parts.detach().cpu().numpy(), g[f"{tag}/loss_parts"][step], rtol=1e-3 if smooth else 3e-3, atol=2e-5)
+        got = parts.detach().cpu().numpy()
+        if smooth or step == 0:
+            np.testing.assert_allclose(got, g[f"{tag}/loss_parts"][step], rtol=1e-3, atol=2e-5)
+        else:
+            assert abs(float(got.sum()) - ref_tot[step]) <= 2.0 * spread[step], (step, float(got.sum()), ref_tot[step], spread[step])
         parts.sum().backward()
         assert abs(opt.param_groups[0]["lr"] - g[f"{tag}/lrs"][step]) < 1e-12
         opt.step()
         sched.step()
-    norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
-    ref = g[f"{tag}/gradnorm_step3"]
-    np.testing.assert_allclose(norms, ref, rtol=5e-3 if smooth else 2e-2, atol=1e-6 * float(ref.max()))
     st = m.state_dict()
-    np.testing.assert_allclose(st["layers.0.batch_norm.running_mean"].cpu().numpy(), g[f"{tag}/rm0"], atol=1e-5)
-    np.testing.assert_allclose(st["layers.0.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv0"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(st["layers.28.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv_last"], rtol=5e-3, atol=1e-5)
     assert int(st["layers.0.batch_norm.num_batches_tracked"]) == int(g[f"{tag}/nbt0"]) == gi.TRAJ_STEPS
+    np.testing.assert_allclose(st["layers.0.batch_norm.running_mean"].cpu().numpy(), g[f"{tag}/rm0"], atol=1e-5 if smooth else 1e-4)
+    np.testing.assert_allclose(st["layers.0.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv0"], rtol=1e-4 if smooth else 1e-3, atol=1e-6)
     pn = np.array([float(p.detach().double().norm()) for p in m.parameters()])
-    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=2e-5)
-    mn = np.array([float(opt.state[p]["momentum_buffer"].double().norm()) for p in m.parameters()])
-    refm = g[f"{tag}/momentum_norms"]
-    np.testing.assert_allclose(mn, refm, rtol=5e-3 if smooth else 2e-2, atol=1e-6 * float(refm.max()))
-    for k in gi.TRAJ_WEIGHT_KEYS:
-        want = g[f"{tag}/w/{k}"]
-        got = st[k].reshape(-1)[::7].cpu().numpy()
-        # the weights moved by sum(lr_t * update_t) ~ 6e-3 * |g|: compare the MOVEMENT, not the (much larger) weights
-        w0 = sd[k].reshape(-1)[::7].numpy()
-        moved = float(np.abs(want - w0).max())
-        assert moved > 0
-        assert float(np.abs(got - want).max()) <= (2e-3 if smooth else 5e-2) * moved + 1e-7, k
+    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=2e-5 if smooth else 1e-3)
+    if smooth:
+        norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+        ref = g[f"{tag}/gradnorm_step3"]
+        np.testing.assert_allclose(norms, ref, rtol=5e-3, atol=1e-6 * float(ref.max()))
+        np.testing.assert_allclose(st["layers.28.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv_last"], rtol=5e-3, atol=1e-5)
+        mn = np.array([float(opt.state[p]["momentum_buffer"].double().norm()) for p in m.parameters()])
+        refm = g[f"{tag}/momentum_norms"]
+        np.testing.assert_allclose(mn, refm, rtol=5e-3, atol=1e-6 * float(refm.max()))
+        for k in gi.TRAJ_WEIGHT_KEYS:
+            want = g[f"{tag}/w/{k}"]
+            got = st[k].reshape(-1)[::7].cpu().numpy()
+            # the weights moved by sum(lr_t * update_t) ~ 6e-3 * |g|: compare the MOVEMENT, not the (much larger) weights
+            w0 = sd[k].reshape(-1)[::7].numpy()
+            moved = float(np.abs(want - w0).max())
+            assert moved > 0
+            assert float(np.abs(got - want).max()) <= 2e-3 * moved + 1e-7, k
 
 
 def test_network_forward_in_channels_1_vs_golden(yt, golden):
@@ -905,7 +918,10 @@ def test_transposing_lds_read_semantics(yt):
 WGRAD16_CASES = [  # cin, cout, k, stride, H, W, N, dz_ld
     (64, 128, 3, 1, 13, 13, 2, 128), (32, 64, 3, 1, 20, 20, 1, 64), (128, 64, 3, 2, 16, 16, 2, 64), (64, 64, 3, 2, 26, 26, 1, 64),
     (256, 128, 1, 1, 13, 13, 3, 128), (128, 21, 1, 1, 10, 10, 2, 32), (96, 255, 1, 1, 7, 7, 1, 256), (192, 96, 3, 1, 19, 38, 1, 96),
-    (64, 32, 1, 1, 52, 52, 1, 32), (512, 64, 3, 1, 5, 5, 4, 64)]
+    (64, 32, 1, 1, 52, 52, 1, 32), (512, 64, 3, 1, 5, 5, 4, 64),
+    # round 3, wgrad3_dma_h16 (3x3 stride 1, cin >= 32): several K slices with the XCD-aware workgroup map and a ragged last
+    # slice; one dW tile with 16 slices; channel counts that are not multiples of the 64-wide tile or of 16
+    (128, 256, 3, 1, 52, 52, 4, 256), (64, 64, 3, 1, 104, 40, 2, 64), (40, 72, 3, 1, 9, 9, 3, 72), (96, 32, 3, 1, 17, 33, 5, 40)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

@@ -212,6 +212,11 @@ size_t wgrad_h16_workspace(int n, int h, int w, int cin, int cout, int ks, int s
 int wgrad_h16_launch(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* partial, int n, int h, int w,
                      int cin, int cout, int ks, int stride, int dtype, int* cout_pad, hipStream_t s);
 int tr_probe_launch(const void* in, void* out, int ld, hipStream_t s);
+// wgrad_dma_h16.hip (3x3 stride-1 weight gradient: LDS-DMA operands, one partial per CU, accumulator-order partials + own reduce)
+bool wgrad_dma_eligible(int cin, int cout, int ks, int stride, int dz_ld, int dz_off, int x_ld, int x_off);
+size_t wgrad_dma_workspace(int n, int h, int w, int cin, int cout);
+int wgrad_dma_launch(const void* dz, int dz_ld, int dz_off, const void* x, int x_ld, int x_off, float* partial, float* dw, int n, int h,
+                     int w, int cin, int cout, int dtype, hipStream_t s);
 // offset (elements) of the fragment-order copy inside a packed weight buffer
 inline size_t v0_packed_elems(int cout, int cin, int ks) { return (size_t)coutpad_of(cout) * kpad_of(cin, ks); }
 
