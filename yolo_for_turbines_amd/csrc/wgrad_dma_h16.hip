@@ -59,6 +59,7 @@ struct WgradDArgs {
     int dz_ld, dz_off, x_ld, x_off;
     int tiles_n, ntile;              // ci tiles; co tiles * ci tiles
     int th_tiles, tw_tiles, total_tiles, tiles_per_slice, nslices;
+    int prio;
 };
 
 __device__ __attribute__((aligned(256))) unsigned int g_wd_zero[64];     // 256 B of zeros (one row of any slot order)
@@ -93,7 +94,8 @@ struct WFrag { u32x2 lo, hi; };
 template <int OFF>
 __device__ __forceinline__ void wd_read(WFrag& f, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                 : "=v"(f.lo), "=v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + 4 * WD_ROWB));
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + 4 * WD_ROWB));   // early clobber: the first read's
+    // data may land in its destination before the second read has been issued, so neither destination may share the address register
 }
 template <int N> __device__ __forceinline__ void wd_wait1(WFrag& a) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.lo), "+v"(a.hi) : "n"(N));
@@ -116,15 +118,23 @@ __device__ __forceinline__ void wd_for(Fn&& fn) {
 
 // Fragment schedule of one K tile. The 18 x-fragments (patch row r, kw) are visited in the row order 0, 5, 1, 4, 2, 3: the rows
 // that feed three MFMAs each come last, and the MFMAs of the last two fragments are DEFERRED behind the tile's barrier, where
-// they cover the latency of the next tile's first reads. Fragment f+3 is requested in step f; the dz fragments a0, a3, a1, a2
-// (first needed in steps 0, 3, 6, 9) ride along in the prologue and in steps 2 and 5.
+// they cover the latency of the next tile's first reads. Fragment f+LA is requested in step f; the dz fragments a0, a3, a1, a2
+// (first needed in steps 0, 3, 6, 9) are requested in the tile's prologue, interleaved with the first LA x-fragments:
+//   a0 B0 a3 B1 a1 B2 a2 [B3 .. B(LA-1)].
 __device__ constexpr int wd_row(int f) { constexpr int ord[6] = {0, 5, 1, 4, 2, 3}; return ord[f / 3]; }
 __device__ constexpr int wd_boff(int f) { return (wd_row(f) * WD_PC + f % 3) * WD_ROWB; }       // + b_off[C & 3]
 __device__ constexpr int wd_bvar(int f) { return (wd_row(f) * WD_PC + f % 3) & 3; }
-__device__ constexpr int wd_wait_of(int f) { return f <= 7 ? 8 : f <= 14 ? 6 : f == 15 ? 4 : f == 16 ? 2 : 0; }
+// reads (2 per fragment) issued after B[f] once step f has made its own request: what `s_waitcnt lgkmcnt` may leave in flight
+__device__ constexpr int wd_wait_of(int f, int LA) {
+    const int bs = 17 - f < LA ? 17 - f : LA;              // x fragments f+1 .. f+LA
+    const int as = f == 0 ? 3 : f == 1 ? 2 : f == 2 ? 1 : 0;   // dz fragments that sit behind B[f] in the prologue order
+    const int n = 2 * (bs + as);
+    return n > 15 ? 15 : n;                                // the counter field is 4 bits: waiting for more is always safe
+}
 
-template <typename T>
+template <typename T, int LA>
 __global__ __launch_bounds__(512) void wgrad3_dma_h16(const WgradDArgs p) {
+    constexpr int NB = LA + 1;                              // x fragments alive at once
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(512) void wgrad3_dma_h16(const WgradDArgs p) {
     for (int k = 0; k < 4; ++k) { dA[k].lo = z2; dA[k].hi = z2; }
     dB[0].lo = z2; dB[0].hi = z2; dB[1] = dB[0];
 
+    if (p.prio && kg == 1) __builtin_amdgcn_s_setprio(1);            // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     int buf = 0;
     for (int it = 0; it < niter; ++it) {
         // ring slot (it + 2) % 3 was read in round it - 1: every wave has passed that round's barrier
@@ -240,13 +251,16 @@ __global__ __launch_bounds__(512) void wgrad3_dma_h16(const WgradDArgs p) {
         unsigned bb[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) bb[v] = b_off[v] + boffs;
-        WFrag A[4], B[4];
-        // prologue reads: a0, B0, B1, a3, B2
+        WFrag A[4], B[NB];
+        // prologue reads: a0 B0 a3 B1 a1 B2 a2 [B3 ..]
         wd_read<0>(A[0], ab);
         wd_read<wd_boff(0)>(B[0], bb[wd_bvar(0)]);
-        wd_read<wd_boff(1)>(B[1], bb[wd_bvar(1)]);
         wd_read<3 * 16 * WD_ROWB>(A[3], ab);
+        wd_read<wd_boff(1)>(B[1], bb[wd_bvar(1)]);
+        wd_read<1 * 16 * WD_ROWB>(A[1], ab);
         wd_read<wd_boff(2)>(B[2], bb[wd_bvar(2)]);
+        wd_read<2 * 16 * WD_ROWB>(A[2], ab);
+        wd_for<3, LA>([&](auto F) { constexpr int f = decltype(F)::value; wd_read<wd_boff(f)>(B[f], bb[wd_bvar(f)]); });
         // the last two fragments of the previous tile: 6 MFMAs while those travel
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -258,27 +272,25 @@ __global__ __launch_bounds__(512) void wgrad3_dma_h16(const WgradDArgs p) {
             constexpr int f = decltype(F)::value;
             constexpr int r = wd_row(f), kw = f % 3;
             if constexpr (f < 6) issue1(std::integral_constant<int, f>{}, nt, nbuf);     // one DMA request per step: 60+ cycles of issue each
-            if constexpr (f == 2) wd_read<1 * 16 * WD_ROWB>(A[1], ab);
-            if constexpr (f == 5) wd_read<2 * 16 * WD_ROWB>(A[2], ab);
-            if constexpr (f + 3 < 18) wd_read<wd_boff(f + 3)>(B[(f + 3) & 3], bb[wd_bvar(f + 3)]);
+            if constexpr (f + LA < 18) wd_read<wd_boff(f + LA)>(B[(f + LA) % NB], bb[wd_bvar(f + LA)]);
             // the dz fragment first needed in this step was requested before B[f]: covered by the same count
-            if constexpr (f == 0) wd_wait2<wd_wait_of(f)>(B[f & 3], A[0]);
-            else if constexpr (f == 3) wd_wait2<wd_wait_of(f)>(B[f & 3], A[3]);
-            else if constexpr (f == 6) wd_wait2<wd_wait_of(f)>(B[f & 3], A[1]);
-            else if constexpr (f == 9) wd_wait2<wd_wait_of(f)>(B[f & 3], A[2]);
-            else wd_wait1<wd_wait_of(f)>(B[f & 3]);
+            if constexpr (f == 0) wd_wait2<wd_wait_of(f, LA)>(B[f % NB], A[0]);
+            else if constexpr (f == 3) wd_wait2<wd_wait_of(f, LA)>(B[f % NB], A[3]);
+            else if constexpr (f == 6) wd_wait2<wd_wait_of(f, LA)>(B[f % NB], A[1]);
+            else if constexpr (f == 9) wd_wait2<wd_wait_of(f, LA)>(B[f % NB], A[2]);
+            else wd_wait1<wd_wait_of(f, LA)>(B[f % NB]);
             if constexpr (f < 16) {
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int k16 = r - kh;
-                    if (k16 >= 0 && k16 < WD_TH) acc[kh * 3 + kw] = WDTraits<T>::mfma(wd_vec(A[k16]), wd_vec(B[f & 3]), acc[kh * 3 + kw]);
+                    if (k16 >= 0 && k16 < WD_TH) acc[kh * 3 + kw] = WDTraits<T>::mfma(wd_vec(A[k16]), wd_vec(B[f % NB]), acc[kh * 3 + kw]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         // fragments 16 and 17 (row 3, kw = 1, 2) have landed (lgkmcnt(0) above): their MFMAs run behind the barrier
         dA[1] = A[1]; dA[2] = A[2]; dA[3] = A[3];
-        dB[0] = B[16 & 3]; dB[1] = B[17 & 3];
+        dB[0] = B[16 % NB]; dB[1] = B[17 % NB];
         wd_wait_vmcnt<6>();                                          // own pieces of tile it + 1 landed (tile it + 2 stays in flight)
         __builtin_amdgcn_s_barrier();                                // ... and everybody else's; everybody is done reading slot buf
         __builtin_amdgcn_sched_barrier(0);
@@ -413,15 +425,19 @@ int wgrad_dma_launch(const void* dz, int dz_ld, int dz_off, const void* x, int x
     a.th_tiles = q.th_tiles; a.tw_tiles = q.tw_tiles; a.total_tiles = q.total_tiles;
     a.tiles_per_slice = q.tiles_per_slice; a.nslices = q.nslices;
     const int grid = a.ntile * a.nslices;
-    if (dtype == YOLO_BF16) {
-        static LdsOnce once;
-        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&wgrad3_dma_h16<__bf16>), WD_LDS, "wgrad3_dma_h16")) return rc;
-        hipLaunchKernelGGL((wgrad3_dma_h16<__bf16>), dim3(grid), dim3(512), WD_LDS, s, a);
-    } else {
-        static LdsOnce once;
-        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&wgrad3_dma_h16<_Float16>), WD_LDS, "wgrad3_dma_h16")) return rc;
-        hipLaunchKernelGGL((wgrad3_dma_h16<_Float16>), dim3(grid), dim3(512), WD_LDS, s, a);
-    }
+    static const int la = getenv("YOLO_WGRAD_LA") ? atoi(getenv("YOLO_WGRAD_LA")) : 3;        // tuning knobs (A/B runs)
+    static const int prio = getenv("YOLO_WGRAD_PRIO") ? atoi(getenv("YOLO_WGRAD_PRIO")) : 0;
+    a.prio = prio;
+    auto go3 = [&](auto kern) -> int {
+        static LdsOnce once;                                // one per instantiation of this generic lambda
+        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), WD_LDS, "wgrad3_dma_h16")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WD_LDS, s, a);
+        return YOLO_OK;
+    };
+    int rc3;
+    if (dtype == YOLO_BF16) rc3 = la == 5 ? go3(&wgrad3_dma_h16<__bf16, 5>) : go3(&wgrad3_dma_h16<__bf16, 3>);
+    else rc3 = la == 5 ? go3(&wgrad3_dma_h16<_Float16, 5>) : go3(&wgrad3_dma_h16<_Float16, 3>);
+    if (rc3) return rc3;
     if (int rc = check_launch("wgrad3_dma_h16")) return rc;
     // reduce: enough threads to keep the chip busy on the small tensors of the high-resolution layers
     const long long total4 = (long long)a.ntile * (WD_TILE_FLOATS / 4);
