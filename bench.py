@@ -171,7 +171,9 @@ def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
     out = dict(boxes_per_s=images * n / dt, images=images, boxes_per_image=n, classes=nc, ms_per_batch=dt * 1e3, kept_mean=kept)
     # the fine-tune class count (2 classes: N^2 / 4 same-class pairs per image) and the clustered generator (SURVEY 8d Config 5 b)
     for name, b2 in (("uniform_2_classes", np.stack([gi.boxes_uniform(n, 2, 1000 + b) for b in range(images)])),
-                     ("clustered_2_classes", np.stack([gi.boxes_clustered(n, 2, 1000 + b, jitter=0.15) for b in range(images)]))):
+                     ("clustered_2_classes", np.stack([gi.boxes_clustered(n, 2, 1000 + b, jitter=0.15) for b in range(images)])),
+                     # SURVEY 8d Config 5 (b) as written: 60 objects per image, ~167 jittered boxes each (sigma = 5 % of the size)
+                     ("clustered_80_classes", np.stack([gi.boxes_clustered(n, nc, 1000 + b) for b in range(images)]))):
         dt2, kept2 = leg(b2)
         out[name] = dict(boxes_per_s=images * n / dt2, ms_per_batch=dt2 * 1e3, kept_mean=kept2)
     return out, batch
@@ -294,6 +296,22 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def kfd_gpu_count():
+    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs), without touching HIP: the launcher parent must
+    not bring up the runtime it then leaves to its children. None when the topology cannot be read."""
+    import glob
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(ln.split()[:2] for ln in open(path) if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if seen else None
+
+
 def self_launch(args):
     import subprocess
     script_args = [a for a in sys.argv[1:] if a != "--dry-launch"]
@@ -301,8 +319,13 @@ def self_launch(args):
     if args.dry_launch:
         print(json.dumps({"argv": argv}))
         return 0
-    n_dev = torch.cuda.device_count()                      # counting devices does not initialise the GPU
-    if n_dev < args.gpus:
+    # A profiler's preloaded library initialises the GPU before this process runs its first line; starting the ranks from
+    # here would then be a launcher hop out of a GPU-initialised process. Profile multi-rank runs by starting torchrun first.
+    if any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        raise SystemExit("bench.py --gpus N was started under a profiler: launch `python -m torch.distributed.run ... bench.py` "
+                         "yourself (see --dry-launch) and put the profiler in front of that")
+    n_dev = kfd_gpu_count()                                # sysfs only: torch.cuda.device_count() may open the HIP runtime
+    if n_dev is not None and n_dev < args.gpus:            # (unreadable topology: let the ranks report)
         raise SystemExit(f"--gpus {args.gpus} but this node shows {n_dev} GPU(s)")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
@@ -492,7 +515,7 @@ def main():
         # there is 416..608, SURVEY 8d widens it to 320..608). 2 timed steps per size after 1 untimed at the new size
         # (plan build + first-touch of ~60 GB of buffers is a per-switch cost the reference pays every 10 batches).
         if not args.no_config3 and world == 1:
-            sizes, b3 = [320, 416, 512, 608], 64
+            sizes, b3 = list(range(320, 609, 32)), 64        # SURVEY 8d Config 3: all ten sizes 320, 352, ..., 608
             per_size, tot_img, tot_t = {}, 0, 0.0
             lf3 = yt.FusedYOLOLoss()
             for S3 in sizes:
@@ -513,7 +536,8 @@ def main():
                 tot_img += b3 * 2
                 tot_t += t3_el
                 del x3, tg3
-            train["config3_multiscale"] = {"workload": "batch 64, 2 classes, bf16 autocast, S in [320,416,512,608], 2 steps per size",
+            train["config3_multiscale"] = {"workload": "batch 64, 2 classes, bf16 autocast, S in 320..608 step 32 (ten sizes), 2 timed "
+                                                       "steps per size after 1 untimed step at the new size",
                                            "value": round(tot_img / tot_t, 2), "unit": "images/s", "images_per_s_by_size": per_size}
             log(f"config3 leg: {tot_img / tot_t:.1f} img/s")
         del tm, opt
@@ -532,8 +556,13 @@ def main():
         def step5():                                    # forward + decode + NMS, one host sync per batch (the NaN guards of the forward)
             yt.detect_images(m5, x5, sa5, 0.45, 0.5, "center")
         t5 = ydist.timed_steps(step5, 10, 2, dist, device)
+        b5, keep5, cnt5 = yt.detect_images(m5, x5, sa5, 0.45, 0.5, "center")
         cfg5 = {"workload": "BASELINE configs[4] per-GPU shape: batch 16, 608x608 fp16 forward + decode (22,743 boxes/image) + per-image NMS",
-                "value": round(16 * world * 10 / t5, 2), "unit": "images/s", "ms_per_step": round(t5 / 10 * 1e3, 3)}
+                "value": round(16 * world * 10 / t5, 2), "unit": "images/s", "ms_per_step": round(t5 / 10 * 1e3, 3),
+                # what the NMS of THIS leg actually consumed (random-init weights: far fewer than the 10,000 post-threshold
+                # boxes per image of SURVEY 8d Config 5, which the `nms` legs below use)
+                "post_threshold_boxes_mean": round(float((b5[..., 4] > 0.5).sum(1).float().mean()), 1),
+                "kept_boxes_mean": round(float(cnt5.float().mean()), 1)}
         del m5
         torch.cuda.empty_cache()
 

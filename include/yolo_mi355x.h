@@ -175,6 +175,31 @@ int yolo_conv_dgrad_s2(const void* dz, int dz_ld, int dz_off, const void* w_pack
 /* upstream gradient in the head layout (B,3,g,g,D) fp32, any strides -> NHWC (B,g,g,ld) in dtype, channel a*D+k, pads 0 */
 int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, int b, int g, int d, int ld, int dtype, void* stream);
 
+/* ---- launch tables for the train-mode forward and the backward (train.py:41-82 run eagerly) -------------------------------- */
+/* The reference's loop issues its step one Python statement at a time; here that is ~900 launches, and issued through an FFI
+ * one by one the host is as slow as the GPU. A table of recorded calls is replayed by ONE call instead (the training
+ * counterpart of yolo_conv_fwd_batch). yolo_call: fn = YOLO_FN_*, a[] = the arguments of that function in declaration order
+ * WITHOUT the trailing stream: integers, size_t and pointers as 64-bit values, float arguments as the bits of a double.
+ * Pointers inside a[] (descriptors, stride arrays, item tables) must stay valid while the table is in use.
+ * yolo_reloc entries, sorted by call: at run time a[arg] of calls[call] is replaced by slots[slot] + offset - for the few pointers
+ * that change from step to step (input batch, prediction tensors, upstream gradients). Stops at the first failing call. */
+enum { YOLO_FN_FILL_ZERO = 1, YOLO_FN_COPY_D2D, YOLO_FN_NCHW_TO_NHWC, YOLO_FN_STEM_FWD, YOLO_FN_CONV_FWD, YOLO_FN_BN_STATS,
+       YOLO_FN_BN_ACT_FWD, YOLO_FN_BN_ACT_BWD, YOLO_FN_UPSAMPLE2X_BWD, YOLO_FN_CONV_WGRAD, YOLO_FN_PACK_WEIGHTS_DGRAD,
+       YOLO_FN_PACK_WEIGHTS_BATCH, YOLO_FN_CONV_DGRAD_S2, YOLO_FN_HEAD_GRAD_TO_NHWC };
+#define YOLO_CALL_MAX_ARGS 22
+typedef struct yolo_call { int32_t fn; int32_t reserved; uint64_t a[YOLO_CALL_MAX_ARGS]; } yolo_call;
+typedef struct yolo_reloc { int32_t call, arg, slot, reserved; int64_t offset; } yolo_reloc;
+int yolo_run_calls(const yolo_call* calls, int n_calls, const yolo_reloc* relocs, int n_relocs, const uint64_t* slots, int n_slots,
+                   void* stream);
+/* the two halves of a fine-tune step (train.py:54 forward in train mode, :67 backward): same table format */
+int yolo_train_fwd_batch(const yolo_call* calls, int n_calls, const yolo_reloc* relocs, int n_relocs, const uint64_t* slots, int n_slots,
+                         void* stream);
+int yolo_train_bwd_batch(const yolo_call* calls, int n_calls, const yolo_reloc* relocs, int n_relocs, const uint64_t* slots, int n_slots,
+                         void* stream);
+/* stream-ordered memset(0) / device-to-device copy: the two non-kernel operations of the step, as table entries */
+int yolo_fill_zero(void* p, size_t bytes, void* stream);
+int yolo_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
 /* ---- letterbox (config.py:101-113: LongestMaxSize -> centred PadIfNeeded(0) -> /255 -> CHW); parity with cv2 UNPINNED --- */
 /* img: uint8 (h, w, 3) on the device; out: fp32 (3, size, size). new_hw / pad_tl (host pointers, may be NULL) receive the
  * resized size and the top / left padding, which un-letterboxing the boxes needs (utils.py:475-501). */

@@ -37,6 +37,12 @@ def test_struct_layout_matches_header(built):
     import ctypes as C
     assert C.sizeof(built.ConvDesc) == 18 * 4
     assert C.sizeof(built.ConvOp) == 18 * 4 + 6 * 8
+    assert C.sizeof(built.Call) == 8 + 8 * built.CALL_MAX_ARGS and C.sizeof(built.Reloc) == 24      # yolo_call / yolo_reloc
+    hdr = open(os.path.join(ROOT, "include", "yolo_mi355x.h")).read()
+    enum = re.search(r"enum \{ (YOLO_FN_FILL_ZERO = 1[^}]*)\}", hdr).group(1)
+    names = [t.split("=")[0].strip() for t in enum.split(",")]
+    assert [n[len("YOLO_FN_"):].lower() for n in names] == [k[len("yolo_"):] for k in built.FN_IDS]   # same order = same ids
+    assert list(built.FN_IDS.values()) == list(range(1, len(names) + 1))
     assert built.lib().yolo_packed_weight_elems(255, 1024, 1) == 2 * 256 * 1024      # row-major + fragment-order copy
     assert built.lib().yolo_packed_weight_elems(32, 3, 3) == 128 * 64
     assert built.lib().yolo_packed_weight_elems(32, 3, 2) == 0

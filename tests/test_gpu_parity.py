@@ -552,7 +552,7 @@ def test_network_train_trajectory_vs_golden(yt, golden, tag, act, opt_kind):
     np.testing.assert_allclose(st["layers.0.batch_norm.running_mean"].cpu().numpy(), g[f"{tag}/rm0"], atol=1e-5 if smooth else 5e-3)
     np.testing.assert_allclose(st["layers.0.batch_norm.running_var"].cpu().numpy(), g[f"{tag}/rv0"], rtol=1e-4 if smooth else 5e-2, atol=1e-6)
     pn = np.array([float(p.detach().double().norm()) for p in m.parameters()])
-    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=2e-5 if smooth else 2e-3)
+    np.testing.assert_allclose(pn, g[f"{tag}/param_norms"], rtol=2e-5 if smooth else 2e-2, atol=0 if smooth else 1e-3)
     if smooth:
         norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
         ref = g[f"{tag}/gradnorm_step3"]

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""How much of the eager fine-tune step is host time? Enqueue N steps without synchronising and compare the time the host
-needed to ENQUEUE them with the time until the GPU has FINISHED them (python tools/host_overhead.py [bf16|fp32] [steps])."""
+"""How much host time does one eager fine-tune step cost (python tools/host_overhead.py [bf16|fp32] [steps])?
+
+Three numbers per configuration:
+  * idle-GPU enqueue: synchronise, then time ONE step's Python (zero_grad, forward, loss, backward, optimizer step) until the
+    last launch has been handed to the runtime - the host cost proper, with an empty queue in front of it;
+  * steady state: N steps without synchronising - host time to enqueue them (once the host is faster than the GPU this reads
+    the GPU's time: the runtime's queue pushes back) and time until the GPU has finished them;
+YOLO_TRAIN_TAPE=0 selects the per-launch path (no launch tables) for A/B."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,19 +25,36 @@ tg = [torch.from_numpy(t).to(dev) for t in gi.synth_targets(B, S, nc, anchors, 3
 x = torch.rand(B, 3, S, S, device=dev)
 lf = yt.FusedYOLOLoss()
 ac = None if dtype == "fp32" else torch.bfloat16
+parts = {}
 
 
-def step():
+def step(timed=False):
+    t = [time.perf_counter()]
     opt.zero_grad(set_to_none=True)
+    t.append(time.perf_counter())
     with torch.autocast("cuda", dtype=ac or torch.bfloat16, enabled=ac is not None):
         preds = m(x)
+        t.append(time.perf_counter())
         loss = sum(sum(lf(preds[i], tg[i], sa[i])) for i in range(3))
+    t.append(time.perf_counter())
     loss.backward()
+    t.append(time.perf_counter())
     opt.step()
+    t.append(time.perf_counter())
+    if timed:
+        for k, name in enumerate(("zero_grad", "forward", "loss", "backward", "optimizer")):
+            parts[name] = parts.get(name, 0.0) + (t[k + 1] - t[k])
 
 
 for _ in range(3):
     step()
+torch.cuda.synchronize()
+idle = []
+for _ in range(steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step(timed=True)
+    idle.append(time.perf_counter() - t0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
@@ -39,13 +62,17 @@ for _ in range(steps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"{dtype}: host enqueue {1e3 * (t1 - t0) / steps:.2f} ms/step, until finished {1e3 * (t2 - t0) / steps:.2f} ms/step")
+idle.sort()
+print(f"{dtype}: idle-GPU enqueue {1e3 * idle[len(idle) // 2]:.2f} ms/step (median of {steps}; "
+      + ", ".join(f"{k} {1e3 * v / steps:.2f}" for k, v in parts.items()) + f") | steady state: host enqueue "
+      f"{1e3 * (t1 - t0) / steps:.2f} ms/step, until finished {1e3 * (t2 - t0) / steps:.2f} ms/step")
 if os.environ.get("HOST_PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile()
+    torch.cuda.synchronize()
     pr.enable()
     for _ in range(3):
         step()
+        torch.cuda.synchronize()
     pr.disable()
-    torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(32)

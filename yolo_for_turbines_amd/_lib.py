@@ -33,6 +33,26 @@ class ConvOp(C.Structure):
     _fields_ = [("d", ConvDesc)] + [(n, C.c_uint64) for n in ("x", "w_packed", "scale", "shift", "residual", "y")]
 
 
+CALL_MAX_ARGS = 22
+
+
+class Call(C.Structure):
+    """`yolo_call` (include/yolo_mi355x.h): one recorded launch of a train-step table."""
+    _fields_ = [("fn", C.c_int32), ("reserved", C.c_int32), ("a", C.c_uint64 * CALL_MAX_ARGS)]
+
+
+class Reloc(C.Structure):
+    """`yolo_reloc`: a[arg] of calls[call] = slots[slot] + offset at run time."""
+    _fields_ = [("call", C.c_int32), ("arg", C.c_int32), ("slot", C.c_int32), ("reserved", C.c_int32), ("offset", C.c_int64)]
+
+
+# YOLO_FN_* of the header, by exported name
+FN_IDS = {name: i + 1 for i, name in enumerate((
+    "yolo_fill_zero", "yolo_copy_d2d", "yolo_nchw_to_nhwc", "yolo_stem_fwd", "yolo_conv_fwd", "yolo_bn_stats", "yolo_bn_act_fwd",
+    "yolo_bn_act_bwd", "yolo_upsample2x_bwd", "yolo_conv_wgrad", "yolo_pack_weights_dgrad", "yolo_pack_weights_batch",
+    "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc"))}
+
+
 class YoloLibError(RuntimeError):
     pass
 
@@ -50,6 +70,11 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p]),
     "yolo_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "yolo_fill_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_copy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_run_calls": (C.c_int, [C.POINTER(Call), C.c_int, C.POINTER(Reloc), C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
+    "yolo_train_fwd_batch": (C.c_int, [C.POINTER(Call), C.c_int, C.POINTER(Reloc), C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
+    "yolo_train_bwd_batch": (C.c_int, [C.POINTER(Call), C.c_int, C.POINTER(Reloc), C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
     "yolo_sgd_chunk_elems": (C.c_int, []),
     "yolo_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "yolo_sgd_step_hp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

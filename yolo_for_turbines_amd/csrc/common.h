@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include "../../include/yolo_mi355x.h"
 
 namespace yolo {

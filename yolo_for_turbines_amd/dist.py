@@ -157,14 +157,44 @@ class GradBuckets:
         bi, off, n, shape = self.slot[id(p)]
         return self.buckets[bi]["buf"].narrow(0, off, n).view(shape)
 
+    def views_for(self, plist, flags):
+        """Fresh gradient views for ``plist`` (None where ``flags`` is False or the parameter has no slot): one split per
+        bucket + one reshape per parameter."""
+        per_bucket = self.__dict__.get("_splits")
+        if per_bucket is None:
+            per_bucket = self._splits = []
+            for bi in range(len(self.buckets)):
+                members = sorted((off, n, pid, shape) for pid, (b, off, n, shape) in self.slot.items() if b == bi)
+                per_bucket.append(([n for _o, n, _p, _s in members], [(pid, shape) for _o, _n, pid, shape in members]))
+        got = {}
+        for b, (sizes, members) in zip(self.buckets, per_bucket):
+            for piece, (pid, shape) in zip(b["buf"].split_with_sizes(sizes), members):
+                got[pid] = piece.view(shape)
+        return [got.get(id(p)) if f else None for p, f in zip(plist, flags)]
+
     def ready(self, p):
-        """The backward has finished writing the gradient of ``p``."""
+        """The backward has finished writing the gradient of ``p``. Returns the bucket index when this completed a bucket whose
+        all-reduce was started, else None."""
         bi = self.slot[id(p)][0]
         b = self.buckets[bi]
         b["pending"] -= 1
         if b["pending"] == 0 and self.dist is not None:
+            self.fire(bi)
+            return bi
+        return None
+
+    def fire(self, bi):
+        """Start the all-reduce of bucket ``bi`` (every gradient in it has been enqueued on the current stream)."""
+        b = self.buckets[bi]
+        b["pending"] = 0
+        if self.dist is not None:
             op = self.dist.ReduceOp.AVG if self.use_avg else self.dist.ReduceOp.SUM
             b["work"] = self.dist.all_reduce(b["buf"], op=op, async_op=True)
+
+    def complete_all(self):
+        """A replayed launch table has written every gradient: nothing is pending (buckets without a collective)."""
+        for b in self.buckets:
+            b["pending"] = 0
 
     def finish(self):
         for b in self.buckets:
