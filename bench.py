@@ -135,8 +135,10 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
         "frac": round(ach / peak, 4),
         # HBM bytes of one launch of the dominant kernel (128->256 3x3 at 52x52, batch 32) from the PMC passes committed under
         # profiles/ (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md)
-        "traffic": (TRAFFIC_F32_C52 if fp32 else TRAFFIC_H16_C52) if at_cfg1 else None,
-        "traffic_source": (("profiles/r01/pmc_hbm_traffic.txt" if fp32 else "profiles/r02/pmc_hbm_traffic.txt") +
+        "traffic": (PMC_TRAFFIC.get("conv_patch_f32" if fp32 else "conv3_dma_h16", (TRAFFIC_F32_C52 if fp32 else TRAFFIC_H16_C52, ""))[0])
+        if at_cfg1 else None,
+        "traffic_source": (PMC_TRAFFIC.get("conv_patch_f32" if fp32 else "conv3_dma_h16",
+                                           (0, "profiles/r01/pmc_hbm_traffic.txt" if fp32 else "profiles/r02/pmc_hbm_traffic.txt"))[1] +
                            " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/conv_bench.py on this kernel; NOT "
                            "measured by the run that printed this line: a process cannot collect PMC counters on itself)"),
         "traffic_unit": ("HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6" if fp32 else
@@ -150,6 +152,16 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
         "whole_step_tflops": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
     }
     return out
+
+
+# HBM bytes per launch of the dominant kernels from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS round's
+# binary (bench.py cannot run a PMC pass on itself): kernel -> (bytes, source file). Filled in by tools/profile_round.sh pmc.
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03", "pmc_traffic.json")) as _f:
+        PMC_TRAFFIC = {k: (v["bytes"], v["source"]) for k, v in json.load(_f).items()}
+except (OSError, ValueError, KeyError):
+    pass
 
 
 def nms_bench(yt, device, images=16, n=10000, nc=80, reps=5):
@@ -196,26 +208,33 @@ def decode_bench(yt, device, batch=32, size=416, nc=80, reps=20):
     ap = (C.c_void_p * 3)(*[a.data_ptr() for a in anchors])
     gg3 = (C.c_int * 3)(*g)
 
-    def run():                                             # what yt.detect() launches: the three scales in one kernel
-        L.check(L.lib().yolo_decode3(pp, st, ap, gg3, batch, nc, out.data_ptr(), n_total, L.current_stream()), "yolo_decode3")
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    def timed(write_back):                                 # what yt.detect() launches: the three scales in one kernel
+        def run():
+            L.check(L.lib().yolo_decode3_ex(pp, st, ap, gg3, batch, nc, write_back, out.data_ptr(), n_total, L.current_stream()),
+                    "yolo_decode3_ex")
         run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    nbytes = batch * n_total * ((5 + nc) * 4 + 4 * 4 + 6 * 4)
-    return {"workload": f"batch {batch}, {size}x{size}, {nc} classes: {n_total} boxes/image, 3 scales in 1 launch", "ms": round(ms, 4),
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms = timed(0)                                          # detect() / detect_images(): predictions left alone
+    ms_wb = timed(1)                                       # cells_to_boxes semantics: sigmoid / exp written back in place
+    nbytes = batch * n_total * ((5 + nc) * 4 + 6 * 4)
+    nbytes_wb = nbytes + batch * n_total * 4 * 4
+    traffic = PMC_TRAFFIC.get("decode3") if (batch, size, nc) == (32, 416, 80) else None
+    return {"workload": f"batch {batch}, {size}x{size}, {nc} classes: {n_total} boxes/image, 3 scales in 1 launch, no in-place "
+                        "write-back (the detect path)", "ms": round(ms, 4),
             "boxes_per_s": round(batch * n_total / ms * 1e3, 1), "algorithmic_bytes": nbytes,
             "roofline": {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
-                         # PMC passes of tools/decode_bench.py (profiles/r01/pmc_hbm_traffic.txt): FETCH_SIZE x2-corrected
-                         # 116.0 MB + WRITE_SIZE 23.3 MB per launch at batch 32, 416x416, 80 classes
-                         "traffic": 139.3e6 if (batch, size, nc) == (32, 416, 80) else None,
-                         "traffic_source": "profiles/r01/pmc_hbm_traffic.txt (separate --pmc passes of tools/decode_bench.py)"}}
+                         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None},
+            "with_write_back": {"workload": "cells_to_boxes semantics (utils.py:106-110): 16 more bytes written into every cell",
+                                "ms": round(ms_wb, 4), "algorithmic_bytes": nbytes_wb,
+                                "achieved_GBps": round(nbytes_wb / ms_wb / 1e6, 1)}}
 
 
 COCO_ANCHORS = [[(0.28, 0.22), (0.38, 0.48), (0.9, 0.78)], [(0.07, 0.15), (0.15, 0.11), (0.14, 0.29)],

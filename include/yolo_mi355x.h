@@ -270,6 +270,11 @@ int yolo_decode(void* pred, const int64_t* strides5, const float* anchors_3x2, i
  * reference's concatenation order (scale 0, 1, 2: demo.py:44-51); boxes (B, n_total, 6) with n_total = sum 3 g_k^2. */
 int yolo_decode3(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
                  float* boxes, int n_total, void* stream);
+/* write_back = 0: the same boxes WITHOUT the reference's in-place sigmoid / exp write-back into the prediction tensors
+ * (utils.py:106-110) - for callers that never look at the predictions again (demo.py:44-55, utils.py:300-321): the kernel's
+ * writes drop to the algorithmic 24 bytes per box. yolo_decode takes the same choice as is_pred = 2. */
+int yolo_decode3_ex(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
+                    int write_back, float* boxes, int n_total, void* stream);
 
 /* Replaces non_max_suppression (utils.py:150-191) with calc_iou (utils.py:38-84) inlined,
  * batched over images. boxes: (B, n, 6) fp32. keep_idx: (B, n) int32, keep_count: (B) int32:

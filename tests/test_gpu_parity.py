@@ -61,7 +61,7 @@ def test_conv_block_every_tile_vs_oracle(yt, i, tile):
     from yolo_for_turbines_amd import engine
     cin, cout, k, s, bn, h = gi.BLOCK_CONFIGS[i]
     blk, x = _block(yt, i, "leaky_relu")
-    engine._module_state.tile_override = tile
+    engine.module_state(blk).tile_override = tile          # per-module knob: no process-wide state is touched
     try:
         if tile >= 5 and (s != 1 or cin % 32):          # patch kernel: stride 1, cin % 32 == 0 only
             from yolo_for_turbines_amd._lib import YoloLibError
@@ -71,7 +71,7 @@ def test_conv_block_every_tile_vs_oracle(yt, i, tile):
         with torch.no_grad():
             y = blk(x.cuda()).cpu()
     finally:
-        engine._module_state.tile_override = None
+        engine.module_state(blk).tile_override = None
     p = gi.block_params(i, cin, cout, k, bn)
     sd = {"b.conv.weight": torch.from_numpy(p["w"])}
     if bn:
@@ -397,7 +397,17 @@ def test_detect_pipeline_vs_oracle(yt):
     sa = [torch.tensor(a) * p.shape[2] for a, p in zip(anchors, preds)]
     pc = [p.clone() for p in preds]
     boxes, keep, count = yt.detect(preds, sa, 0.45, 0.5, "center")
-    ref_boxes = torch.cat([opp.cells_to_boxes(p.cpu(), a, p.shape[2]) for p, a in zip(pc, sa)], dim=1).numpy()
+    for p, q in zip(preds, pc):                # the detect path leaves the prediction tensors alone (no caller reads them again) ...
+        assert torch.equal(p, q)
+    pm = [p.clone() for p in pc]
+    boxes_m, keep_m, count_m = yt.detect(pm, sa, 0.45, 0.5, "center", mutate=True)
+    assert torch.equal(boxes, boxes_m) and torch.equal(count, count_m)
+    for b in range(3):                         # (entries of keep beyond count are unspecified)
+        assert torch.equal(keep[b, :int(count[b])], keep_m[b, :int(count_m[b])])
+    pcpu = [p.cpu() for p in pc]
+    ref_boxes = torch.cat([opp.cells_to_boxes(p, a, p.shape[2]) for p, a in zip(pcpu, sa)], dim=1).numpy()
+    for p, q in zip(pm, pcpu):                 # ... and mutate=True reproduces cells_to_boxes' in-place side effect (utils.py:106-110)
+        np.testing.assert_allclose(p.cpu().numpy(), q.numpy(), rtol=3e-6, atol=1e-7)
     got = boxes.cpu().numpy()
     np.testing.assert_allclose(got[..., :5], ref_boxes[..., :5], rtol=3e-6, atol=1e-7)
     np.testing.assert_array_equal(got[..., 5], ref_boxes[..., 5])
@@ -665,6 +675,13 @@ def test_network_train_step_leaky_vs_fp64_on_matched_branches(yt, golden):
           + ", ".join(f"{k.split('.conv')[0].split('.batch')[0]}={v:.1f}" for k, v in ratios.items()))
     assert differ <= 64, differ                                   # a handful of |u| ~ 1e-6 elements out of ~8.6 M
     assert worst <= 1e-3, (worst_key, worst)
+    # Un-matched comparison, asserted where it can be: the head convolutions sit behind at most one LeakyReLU whose flipped
+    # elements reach them, so there |ours - fp64| stays within a small multiple of the reference's own fp32 error
+    # (measured 0.7 - 1.7; the early layers, where a flipped branch moves a whole gradient column, read 7 - 15 and are
+    # covered by the matched-branch bound above)
+    for key, v in ratios.items():
+        if ".pred_block.1." in key:
+            assert v <= 3.0, (key, v)
 
 
 # ------------------------------------------------------------- multi-scale sizes (train.py:45-46)
@@ -736,12 +753,12 @@ def test_conv_block_16bit_vs_oracle(yt, i, dtype):
         sd["b.conv.bias"] = torch.from_numpy(p["bias"])
     with torch.no_grad():
         ref = onet.cnn_block(sd, dict(prefix="b", cin=cin, cout=cout, k=k, stride=s, bn=bn), x, "leaky_relu")
-    engine._module_state.compute_dtype = dtype
+    engine.module_state(blk).compute_dtype = dtype
     try:
         with torch.no_grad():
             y = blk(x.cuda()).cpu()
     finally:
-        engine._module_state.compute_dtype = None
+        engine.module_state(blk).compute_dtype = None
     assert y.shape == ref.shape and y.dtype == torch.float32
     err = float((y - ref).abs().max() / ref.abs().max())
     assert err <= H16_TOL[dtype], f"cfg {i} {dtype}: rel err {err}"
@@ -831,13 +848,13 @@ def test_block_train_16bit_vs_golden(yt, golden, i, act, dtype):
     blk.train()
     tag = f"cfg{i}/{act}"
     xg = x.cuda().requires_grad_(True)
-    engine._module_state.compute_dtype = dtype
+    engine.module_state(blk).compute_dtype = dtype
     try:
         y = blk(xg)
         gy = torch.from_numpy(np.random.Generator(np.random.PCG64(3000 + i)).standard_normal(tuple(y.shape), dtype=np.float32))
         y.backward(gy.cuda())
     finally:
-        engine._module_state.compute_dtype = None
+        engine.module_state(blk).compute_dtype = None
     tol = H16_TRAIN_TOL[dtype]
 
     def close(got, want, what, t=tol):

@@ -126,6 +126,8 @@ _SIGS = {
                               C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "yolo_decode3": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p]),
+    "yolo_decode3_ex": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "yolo_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -124,7 +124,10 @@ __device__ __forceinline__ void decode_block(float* __restrict__ pred, long long
         p2 = expf(p2) * anchors[2 * a];
         p3 = expf(p3) * anchors[2 * a + 1];
         p4 = sigmoid_f(p4);
-        gp[0] = p0; gp[sk] = p1; gp[2 * sk] = p2; gp[3 * sk] = p3;   // in-place side effect (utils.py:106-110)
+        // in-place side effect (utils.py:106-110): what cells_to_boxes does to its argument. is_pred == 2 (detect paths, where
+        // the caller cannot observe the prediction tensor afterwards) leaves it alone: 16 bytes into every (5+nc)*4-byte cell
+        // are a partial-line write per cell, 1.7x the algorithmic 24 bytes per box of this kernel's writes
+        if (is_pred == 1) { gp[0] = p0; gp[sk] = p1; gp[2 * sk] = p2; gp[3 * sk] = p3; }
     } else {
         cls = src[5 * kstride];
     }
@@ -146,12 +149,12 @@ __global__ void decode_kernel(float* __restrict__ pred, long long sb, long long 
 // the three scales of one forward in ONE launch (demo.py:44-51 / utils.py:300-309 order): at batch 32 the three separate
 // launches were launch-latency-bound (3 x ~25 us for 129 MB)
 struct DecodeScale { float* pred; long long sb, sa, sy, sx, sk; const float* anchors; int g, box_offset; long long first_block; };
-struct Decode3Args { DecodeScale sc[3]; int B, nc, n_total; float* boxes; };
+struct Decode3Args { DecodeScale sc[3]; int B, nc, n_total, is_pred; float* boxes; };
 
 __global__ void decode3_kernel(const Decode3Args a) {
     const int k = (long long)blockIdx.x >= a.sc[2].first_block ? 2 : ((long long)blockIdx.x >= a.sc[1].first_block ? 1 : 0);
     const DecodeScale& d = a.sc[k];
-    decode_block(d.pred, d.sb, d.sa, d.sy, d.sx, d.sk, d.anchors, a.B, d.g, a.nc, 1, a.boxes, a.n_total, d.box_offset,
+    decode_block(d.pred, d.sb, d.sa, d.sy, d.sx, d.sk, d.anchors, a.B, d.g, a.nc, a.is_pred, a.boxes, a.n_total, d.box_offset,
                  (long long)blockIdx.x - d.first_block);
 }
 
@@ -1373,9 +1376,14 @@ int yolo_decode(void* pred, const int64_t* s, const float* anchors, int b, int g
 
 int yolo_decode3(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
                  float* boxes, int n_total, void* stream) {
+    return yolo_decode3_ex(preds3, strides15, anchors3, grids3, b, nc, 1, boxes, n_total, stream);
+}
+
+int yolo_decode3_ex(void* const* preds3, const int64_t* strides15, const float* const* anchors3, const int* grids3, int b, int nc,
+                    int write_back, float* boxes, int n_total, void* stream) {
     if (!preds3 || !strides15 || !anchors3 || !grids3 || !boxes || b <= 0 || nc < 1) return fail(YOLO_ERR_ARG, "decode3: bad arguments");
     Decode3Args a;
-    a.B = b; a.nc = nc; a.n_total = n_total; a.boxes = boxes;
+    a.B = b; a.nc = nc; a.n_total = n_total; a.boxes = boxes; a.is_pred = write_back ? 1 : 2;
     long long blocks = 0;
     int off = 0;
     for (int k = 0; k < 3; ++k) {

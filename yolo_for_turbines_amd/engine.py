@@ -599,7 +599,15 @@ class ModelState:
 
 
 # ------------------------------------------------------------------ stand-alone sub-modules
-_module_state = ModelState()
+def module_state(module) -> ModelState:
+    """The engine state of a block that is called on its own (model_tests.py:16-45 call CNNBlock / ResidualBlock /
+    ScalePredictionBlock directly): created on first use and kept ON THE MODULE (`module._engine`, like `YOLOv3._engine`), so
+    knobs such as `tile_override` / `compute_dtype` are per object - the library keeps no process-wide mutable state besides
+    its handle caches."""
+    st = module.__dict__.get("_engine")
+    if st is None:
+        st = module.__dict__["_engine"] = ModelState()
+    return st
 
 
 def run_module_nchw(module, x):
@@ -613,7 +621,8 @@ def run_module_nchw(module, x):
         return train_engine.run_module_train(module, x)
     lib = L.lib()
     B, Cc, H, W = x.shape
-    dt = resolve_dtype(_module_state.compute_dtype)
+    st = module_state(module)
+    dt = resolve_dtype(st.compute_dtype)
     with torch.cuda.device(x.device):
         stream = L.current_stream()
         prog = Program(B)
@@ -631,17 +640,17 @@ def run_module_nchw(module, x):
         else:
             raise NotImplementedError(type(module).__name__)
         try:
-            return _run_module_plan(module, x, prog, cur, out, stream, dt)
+            return _run_module_plan(st, module, x, prog, cur, out, stream, dt)
         finally:
-            _module_state.invalidate(drop_plans=True)
+            st.invalidate(drop_plans=True)
 
 
-def _run_module_plan(module, x, prog, cur, out, stream, dt="fp32"):
+def _run_module_plan(st, module, x, prog, cur, out, stream, dt="fp32"):
     lib = L.lib()
     B, Cc, H, W = x.shape
     cpad = cur.ld
-    plan = Plan(prog, _module_state, x.device, _module_state.tile_override, use_stem=not _module_state.tile_override, dtype=dt)
-    _module_state.refresh_weights(plan.blocks, x.device, stream, dt)
+    plan = Plan(prog, st, x.device, st.tile_override, use_stem=not st.tile_override, dtype=dt)
+    st.refresh_weights(plan.blocks, x.device, stream, dt)
     xin = x.detach().float().contiguous()
     plan.load_input(xin, stream)
     result = None

@@ -625,11 +625,12 @@ def forward_train(state, model, x):
 
 def run_module_train(module, x):
     """Stand-alone CNNBlock / ResidualBlock in training mode under autograd (block-level parity tests)."""
-    from .engine import _module_state
+    from .engine import module_state
     from .model import CNNBlock, ResidualBlock
     B, Cc, H, W = x.shape
     with torch.cuda.device(x.device):
-        dt = resolve_dtype(_module_state.compute_dtype)
+        mst = module_state(module)
+        dt = resolve_dtype(mst.compute_dtype)
         prog = Program(B)
         al = 8 if dt != "fp32" else 4
         cpad = (Cc + al - 1) // al * al
@@ -642,7 +643,7 @@ def run_module_train(module, x):
         else:
             raise NotImplementedError("stand-alone training is provided for CNNBlock and ResidualBlock")
         plan = TrainPlan(prog, x.device, dt)
-        return _ModuleTrainFn.apply(x, (_module_state, module, plan, out), *list(module.parameters()))
+        return _ModuleTrainFn.apply(x, (mst, module, plan, out), *list(module.parameters()))
 
 
 class _ModuleTrainFn(torch.autograd.Function):

@@ -50,18 +50,18 @@ def calc_iou(boxes1, boxes2, box_format="center"):
 
 
 # ------------------------------------------------------------------------------ decode
-def decode_boxes(predictions, anchors, grid_size=None, is_pred=True, out=None, box_offset=0):
+def decode_boxes(predictions, anchors, grid_size=None, is_pred=True, out=None, box_offset=0, mutate=True):
     """Device decode of one scale: (B,3,g,g,5+nc) -> (B, 3*g*g, 6) fp32 tensor
     [cx,cy,w,h,obj,cls] normalised to [0,1]; mutates ``predictions[...,0:4]`` in place when
-    ``is_pred`` exactly like the reference (utils.py:106-110). ``out`` / ``box_offset`` let
+    ``is_pred`` exactly like the reference (utils.py:106-110) unless ``mutate=False``. ``out`` / ``box_offset`` let
     several scales share one (B, N_total, 6) buffer."""
     if not predictions.is_cuda:
         raise RuntimeError("decode_boxes runs on MI355X only (no CPU fallback)")
     if predictions.dtype in (torch.float16, torch.bfloat16):
         # heads handed out under autocast: decode an fp32 copy and write the in-place side effect (utils.py:106-110) back
         p32 = predictions.float()
-        res = decode_boxes(p32, anchors, grid_size, is_pred, out, box_offset)
-        if is_pred:
+        res = decode_boxes(p32, anchors, grid_size, is_pred, out, box_offset, mutate)
+        if is_pred and mutate:
             predictions[..., 0:4] = p32[..., 0:4].to(predictions.dtype)
         return res
     if predictions.dtype != torch.float32:
@@ -79,7 +79,7 @@ def decode_boxes(predictions, anchors, grid_size=None, is_pred=True, out=None, b
         if is_pred else None
     strides = (C.c_int64 * 5)(*predictions.stride())
     with torch.cuda.device(predictions.device):
-        L.check(L.lib().yolo_decode(predictions.data_ptr(), strides, L.ptr(anc), B, g, D - 5, int(bool(is_pred)),
+        L.check(L.lib().yolo_decode(predictions.data_ptr(), strides, L.ptr(anc), B, g, D - 5, (1 if mutate else 2) if is_pred else 0,
                                     out.data_ptr(), out.shape[1], int(box_offset), L.current_stream()), "yolo_decode")
     return out
 
@@ -141,11 +141,13 @@ def non_max_suppression(boxes, iou_threshold, obj_threshold, box_format="corners
     return t[keep[:k].long()].tolist() if k else []
 
 
-def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, box_format="center"):
+def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, box_format="center", mutate=False):
     """Fused post-processing of a forward pass (the sequence of demo.py:44-55 /
     utils.py:300-321, all images at once, nothing leaves HBM):
     decode three scales into one (B, N, 6) buffer in the reference's concatenation order
-    (scale 0, 1, 2), then per-image NMS. Returns (boxes (B,N,6), keep_idx (B,N), keep_count (B,))."""
+    (scale 0, 1, 2), then per-image NMS. Returns (boxes (B,N,6), keep_idx (B,N), keep_count (B,)).
+    ``mutate=True`` also performs the in-place sigmoid / exp write-back ``cells_to_boxes`` does to the prediction tensors
+    (utils.py:106-110); the reference's callers of this sequence never read them again, so the default leaves them alone."""
     B = predictions[0].shape[0]
     n_per = [3 * p.shape[2] * p.shape[2] for p in predictions]
     total = sum(n_per)
@@ -159,12 +161,12 @@ def detect(predictions, scaled_anchors, iou_threshold=0.45, obj_threshold=0.5, b
             st = (C.c_int64 * 15)(*[v for p in predictions for v in p.stride()])
             ap = (C.c_void_p * 3)(*[a.data_ptr() for a in anc])
             gg = (C.c_int * 3)(*[p.shape[2] for p in predictions])
-            L.check(L.lib().yolo_decode3(pp, st, ap, gg, B, predictions[0].shape[4] - 5, boxes.data_ptr(), total, L.current_stream()),
-                    "yolo_decode3")
+            L.check(L.lib().yolo_decode3_ex(pp, st, ap, gg, B, predictions[0].shape[4] - 5, int(bool(mutate)), boxes.data_ptr(), total,
+                                            L.current_stream()), "yolo_decode3")
     else:
         off = 0
         for p, a, n in zip(predictions, scaled_anchors, n_per):
-            decode_boxes(p, a, p.shape[2], True, out=boxes, box_offset=off)
+            decode_boxes(p, a, p.shape[2], True, out=boxes, box_offset=off, mutate=mutate)
             off += n
     keep, count = nms_indices(boxes, iou_threshold, obj_threshold, box_format)
     return boxes, keep, count
