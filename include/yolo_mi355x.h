@@ -140,6 +140,17 @@ size_t yolo_bn_workspace_bytes(int m, int c);
 int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gamma, const float* beta, float momentum,
                   float eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                   float* shift, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The statistics pass fused into the producing convolution (16-bit kernels on LDS-DMA: 3x3 stride 1 with > 64 output channels,
+ * 1x1 with >= 128 input and output channels): yolo_conv_fwd_stats = the raw convolution (identity epilogue: act NONE, no
+ * residual, YOLO_OUT_NHWC) that also writes per-wave partial sums of z and z^2 (of the ROUNDED values it stores) as
+ * stats[row][2][ld] fp32; yolo_bn_stats_from_partials = the second half of yolo_bn_stats on those rows (same outputs, fp64
+ * across rows in a fixed order). yolo_conv_stats_rows: rows (and *ld) for a descriptor, 0 = no fused kernel for it. */
+int yolo_conv_stats_rows(const yolo_conv_desc* d, int* ld);
+int yolo_conv_fwd_stats(const yolo_conv_desc* d, const void* x, const void* w_packed, void* z, float* stats, size_t stats_bytes,
+                        void* stream);
+int yolo_bn_stats_from_partials(const float* partial, int rows, int ld, int m, int c, const float* gamma, const float* beta,
+                                float momentum, float eps, float* running_mean, float* running_var, float* mean, float* invstd,
+                                float* scale, float* shift, void* stream);
 /* y = act((z - mean)*scale + shift) [+ residual] (mean may be NULL = 0); out_mode YOLO_OUT_NHWC or
  * YOLO_OUT_UPSAMPLE2X. */
 int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const void* residual,
@@ -185,7 +196,8 @@ int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, 
  * that change from step to step (input batch, prediction tensors, upstream gradients). Stops at the first failing call. */
 enum { YOLO_FN_FILL_ZERO = 1, YOLO_FN_COPY_D2D, YOLO_FN_NCHW_TO_NHWC, YOLO_FN_STEM_FWD, YOLO_FN_CONV_FWD, YOLO_FN_BN_STATS,
        YOLO_FN_BN_ACT_FWD, YOLO_FN_BN_ACT_BWD, YOLO_FN_UPSAMPLE2X_BWD, YOLO_FN_CONV_WGRAD, YOLO_FN_PACK_WEIGHTS_DGRAD,
-       YOLO_FN_PACK_WEIGHTS_BATCH, YOLO_FN_CONV_DGRAD_S2, YOLO_FN_HEAD_GRAD_TO_NHWC };
+       YOLO_FN_PACK_WEIGHTS_BATCH, YOLO_FN_CONV_DGRAD_S2, YOLO_FN_HEAD_GRAD_TO_NHWC, YOLO_FN_CONV_FWD_STATS,
+       YOLO_FN_BN_STATS_FROM_PARTIALS };
 #define YOLO_CALL_MAX_ARGS 22
 typedef struct yolo_call { int32_t fn; int32_t reserved; uint64_t a[YOLO_CALL_MAX_ARGS]; } yolo_call;
 typedef struct yolo_reloc { int32_t call, arg, slot, reserved; int64_t offset; } yolo_reloc;

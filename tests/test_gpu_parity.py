@@ -1551,6 +1551,63 @@ def test_dma_conv_kernels_edge_shapes(yt, case, dtype):
     keep[y_off:y_off + cout] = False
     assert torch.equal(got[..., keep], y0[..., keep])                           # neighbouring channels of the buffer untouched
 
+FUSED_STATS_CASES = [  # B, H, cin, cout, k: 3x3 / 1x1 LDS-DMA kernels; ragged and image-straddling tiles, channel tiles with padding
+    (2, 13, 64, 128, 3), (3, 7, 96, 72, 3), (1, 52, 128, 256, 3), (4, 26, 128, 136, 3), (2, 13, 256, 128, 1), (1, 19, 128, 200, 1),
+    (3, 5, 384, 128, 1)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", FUSED_STATS_CASES)
+def test_conv_epilogue_batchnorm_statistics(yt, case, dtype):
+    """yolo_conv_fwd_stats + yolo_bn_stats_from_partials (train-mode forward: batch statistics from the convolution's epilogue)
+    against (a) the same convolution through yolo_conv_fwd: z bit-identical, and (b) yolo_bn_stats on that z and an fp64 mean /
+    variance of the stored values: mean, invstd, scale, shift and the running-statistic update."""
+    from yolo_for_turbines_amd import _lib as L
+    B, H, cin, cout, k = case
+    code, tdt = {"bf16": (L.BF16, torch.bfloat16), "fp16": (L.F16, torch.float16)}[dtype]
+    g = torch.Generator().manual_seed(77 + cin + 3 * cout + H)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    x = (torch.randn((B, H, H, cin), generator=g) + 0.3).to(tdt).to(dev)
+    w = (torch.randn((cout, cin, k, k), generator=g) * (1.0 / (cin * k * k)) ** 0.5).to(dev)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, k, code), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights(w.data_ptr(), wp.data_ptr(), cout, cin, k, code, st))
+    d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=1, x_ld=cin, x_off=0, y_ld=cout, y_off=0, r_ld=0, r_off=0, act=0,
+                   out_mode=L.OUT_NHWC, dtype=code, flags=0, tile=0)
+    import ctypes as C
+    ld = C.c_int(0)
+    rows = lib.yolo_conv_stats_rows(d, C.byref(ld))
+    assert rows > 0 and ld.value >= cout
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    m = B * H * H
+    z_ref = torch.full((m, cout), 7.0, dtype=tdt, device=dev)
+    z = torch.full((m, cout), 7.0, dtype=tdt, device=dev)
+    L.check(lib.yolo_conv_fwd(d, x.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z_ref.data_ptr(), 0, st), "conv")
+    part = torch.full((rows * 2 * ld.value,), float("nan"), dtype=torch.float32, device=dev)
+    L.check(lib.yolo_conv_fwd_stats(d, x.data_ptr(), wp.data_ptr(), z.data_ptr(), part.data_ptr(), part.numel() * 4, st), "conv_fwd_stats")
+    assert torch.equal(z, z_ref)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+
+    def stats(fused):
+        rm, rv = torch.full((cout,), 0.25, device=dev), torch.full((cout,), 2.0, device=dev)
+        out = [torch.empty(cout, device=dev) for _ in range(4)]
+        if fused:
+            L.check(lib.yolo_bn_stats_from_partials(part.data_ptr(), rows, ld.value, m, cout, gamma.data_ptr(), beta.data_ptr(), 0.1, 1e-5,
+                                                    rm.data_ptr(), rv.data_ptr(), *[t.data_ptr() for t in out], st), "from_partials")
+        else:
+            ws = torch.empty(lib.yolo_bn_workspace_bytes(m, cout), dtype=torch.uint8, device=dev)
+            L.check(lib.yolo_bn_stats(z.data_ptr(), m, cout, cout, 0, gamma.data_ptr(), beta.data_ptr(), 0.1, 1e-5, rm.data_ptr(), rv.data_ptr(),
+                                      *[t.data_ptr() for t in out], code, ws.data_ptr(), ws.numel(), st), "bn_stats")
+        return [t.cpu().double() for t in out + [rm, rv]]
+    a, b = stats(True), stats(False)
+    z64 = z.cpu().double()
+    mu, var = z64.mean(0), z64.var(0, unbiased=False)
+    np.testing.assert_allclose(a[0].numpy(), mu.numpy(), rtol=0, atol=2e-6 * float(z64.abs().max()))
+    np.testing.assert_allclose(a[1].numpy(), (1.0 / torch.sqrt(var + 1e-5)).numpy(), rtol=5e-6)
+    for u, v in zip(a, b):                      # and the separate statistics pass agrees (both sum the stored, rounded values)
+        np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=5e-6, atol=1e-6)
+    assert not bool(torch.isnan(part.view(rows, 2, ld.value)[:, :, :cout]).any())
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(1, 32, 32), (3, 37, 45), (2, 5, 3), (1, 1, 70), (2, 96, 96), (1, 416, 416)])
 def test_stem_block_on_the_matrix_cores(yt, shape, dtype):

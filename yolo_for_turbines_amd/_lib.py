@@ -50,7 +50,7 @@ class Reloc(C.Structure):
 FN_IDS = {name: i + 1 for i, name in enumerate((
     "yolo_fill_zero", "yolo_copy_d2d", "yolo_nchw_to_nhwc", "yolo_stem_fwd", "yolo_conv_fwd", "yolo_bn_stats", "yolo_bn_act_fwd",
     "yolo_bn_act_bwd", "yolo_upsample2x_bwd", "yolo_conv_wgrad", "yolo_pack_weights_dgrad", "yolo_pack_weights_batch",
-    "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc"))}
+    "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc", "yolo_conv_fwd_stats", "yolo_bn_stats_from_partials"))}
 
 
 class YoloLibError(RuntimeError):
@@ -91,6 +91,10 @@ _SIGS = {
     "yolo_bn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_size_t, C.c_void_p]),
+    "yolo_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+    "yolo_conv_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_bn_stats_from_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_bn_act_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),

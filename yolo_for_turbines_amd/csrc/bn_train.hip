@@ -194,6 +194,53 @@ __global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, 
     }
 }
 
+// The same finalize from the per-wave partial sums a convolution's epilogue wrote (conv_h16.hip: d_epilogue_stats):
+// partial[row][2][ld] fp32, row = a wave's 64 pixels; fp64 across rows in a fixed order (lane l adds rows l, l + 64, ...,
+// then the lanes in order), i.e. deterministic like the path above.
+__global__ void bn_stats_finalize_rows(const float* __restrict__ partial, int nrows, int ld, int m, int c, float momentum, float eps,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                       float* __restrict__ shift) {
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int lc = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
+    const int ch = blockIdx.x * FIN_CH + lc;
+    double s = 0, q = 0;
+    if (ch < c) {
+        const float* src = partial + ch;
+        const size_t step = (size_t)2 * ld;
+        int r = lane;
+        for (; r + 3 * FIN_LANES < nrows; r += 4 * FIN_LANES) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = src[(size_t)(r + u * FIN_LANES) * step]; b[u] = src[(size_t)(r + u * FIN_LANES) * step + ld]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; r < nrows; r += FIN_LANES) { s += src[(size_t)r * step]; q += src[(size_t)r * step + ld]; }
+    }
+    red[lane][lc][0] = s;
+    red[lane][lc][1] = q;
+    __syncthreads();
+    if (lane != 0 || ch >= c) return;
+    s = 0; q = 0;
+#pragma unroll 4
+    for (int l = 0; l < FIN_LANES; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }
+    const double mu = s / m;
+    double var = q / m - mu * mu;
+    if (var < 0) var = 0;
+    const float is = 1.0f / sqrtf((float)var + eps);
+    mean[ch] = (float)mu;
+    invstd[ch] = is;
+    scale[ch] = gamma[ch] * is;
+    shift[ch] = beta[ch];
+    if (running_mean) {
+        const double unbiased = m > 1 ? var * m / (m - 1) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+}
+
 // y = act((z - mean)*scale + shift) [+ residual], same output modes as the conv epilogue. Thread layout of the reductions
 // (a thread owns one 16-byte channel vector and walks pixels): the per-channel parameters are loaded ONCE per thread, no
 // index division per element, AP_MLP pixels in flight. (The first version was a flat grid-stride loop over (pixel, vector)
@@ -536,6 +583,37 @@ int yolo_bn_stats(const void* z, int m, int c, int ld, int off, const float* gam
     hipLaunchKernelGGL(bn_stats_finalize, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, s, (const double*)workspace, nblk, m, c, momentum,
                        eps, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
     return check_launch("bn_stats_finalize");
+}
+
+/* rows / channel stride of the BatchNorm partial sums yolo_conv_fwd_stats would write for this convolution (0 rows: it has no
+ * fused-statistics kernel and the caller runs yolo_bn_stats on z instead) */
+int yolo_conv_stats_rows(const yolo_conv_desc* d, int* ld) {
+    if (ld) *ld = 0;
+    if (!d || d->dtype == YOLO_F32) return 0;
+    int rl[2] = {0, 0};
+    if (conv_h16_launch_stats(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rl, nullptr, nullptr) != YOLO_OK) {
+        return 0;
+    }
+    if (ld) *ld = rl[1];
+    return rl[0];
+}
+
+int yolo_conv_fwd_stats(const yolo_conv_desc* d, const void* x, const void* w_packed, void* z, float* stats, size_t stats_bytes,
+                        void* stream) {
+    if (!d || !x || !w_packed || !z || !stats) return fail(YOLO_ERR_ARG, "conv_fwd_stats: null pointer");
+    if (d->dtype == YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "conv_fwd_stats: 16-bit convolutions only");
+    int rl[2];
+    return conv_h16_launch_stats(d, x, w_packed, nullptr, nullptr, nullptr, z, nullptr, stats, rl, &stats_bytes, (hipStream_t)stream);
+}
+
+int yolo_bn_stats_from_partials(const float* partial, int rows, int ld, int m, int c, const float* gamma, const float* beta,
+                                float momentum, float eps, float* running_mean, float* running_var, float* mean, float* invstd,
+                                float* scale, float* shift, void* stream) {
+    if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift) return fail(YOLO_ERR_ARG, "bn_stats_from_partials: null pointer");
+    if (rows <= 0 || m <= 0 || c <= 0 || ld < c) return fail(YOLO_ERR_ARG, "bn_stats_from_partials: bad shape");
+    hipLaunchKernelGGL(bn_stats_finalize_rows, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, (hipStream_t)stream, partial, rows, ld, m, c,
+                       momentum, eps, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+    return check_launch("bn_stats_finalize_rows");
 }
 
 int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const void* residual,

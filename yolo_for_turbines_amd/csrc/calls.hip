@@ -91,6 +91,13 @@ int run_one(int fn, const uint64_t* a, void* s) {
     case YOLO_FN_HEAD_GRAD_TO_NHWC:
         return yolo_head_grad_to_nhwc(p_of<const float>(a[0]), p_of<const int64_t>(a[1]), p_of<void>(a[2]), (int)a[3], (int)a[4],
                                       (int)a[5], (int)a[6], (int)a[7], s);
+    case YOLO_FN_CONV_FWD_STATS:
+        return yolo_conv_fwd_stats(p_of<const yolo_conv_desc>(a[0]), p_of<const void>(a[1]), p_of<const void>(a[2]), p_of<void>(a[3]),
+                                   p_of<float>(a[4]), (size_t)a[5], s);
+    case YOLO_FN_BN_STATS_FROM_PARTIALS:
+        return yolo_bn_stats_from_partials(p_of<const float>(a[0]), (int)a[1], (int)a[2], (int)a[3], (int)a[4], p_of<const float>(a[5]),
+                                           p_of<const float>(a[6]), f_of(a[7]), f_of(a[8]), p_of<float>(a[9]), p_of<float>(a[10]),
+                                           p_of<float>(a[11]), p_of<float>(a[12]), p_of<float>(a[13]), p_of<float>(a[14]), s);
     default:
         return fail(YOLO_ERR_ARG, "run_calls: unknown function id %d", fn);
     }

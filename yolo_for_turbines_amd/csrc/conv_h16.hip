@@ -51,6 +51,8 @@ struct ConvHArgs {
     int prio;                            // conv3_dma_h16: prologue / epilogue at s_setprio 2 (A/B switch YOLO_DMA_PRIO=0)
     unsigned qperm;                      // conv3_dma_h16: nibble q = pixel quad of lane quad q within a 32-pixel m-tile
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
+    float* stats;                        // DMA kernels, training: per-wave BatchNorm partial sums [row][2][stats_ld] (null: ordinary epilogue)
+    int stats_ld;
     // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
     // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
     unsigned mg_H, mg_TW, mg_PC, mg_tn, mg_tw, mg_Hp;
@@ -991,6 +993,117 @@ __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&ac
 }
 
 
+// ---- epilogue of the train-mode forward: raw convolution output z (no scale / shift / activation / residual) AND the
+// BatchNorm partial sums of this wave's 64 pixels x 64 channels, so that the statistics pass over z (one full read of every
+// conv output: 0.7 ms of the 17 ms bf16 step) disappears. Sums are taken of the ROUNDED values, i.e. of exactly what is
+// stored and normalised later (the reference's batch_norm sees the 16-bit conv output too).
+// After the half exchange of d_epilogue a lane holds 8 consecutive channels of ONE pixel per (n-tile j, channel pair kp) and
+// m-tile i: 2 (sum, sum of squares) x 2 x 2 x 8 = 64 per-lane values, each to be added over the 32 pixels (lanes) of its half.
+// A reduce-scatter butterfly does that in 31 + 31 adds instead of 64 x 5: every level pairs two registers and two lane groups,
+// each group keeps one register of the pair and receives the partner group's copy of it:
+//   level 16: v_permlane16_swap (odd rows of X <-> even rows of Y), pair = (sum, sum of squares)  -> bit 4 of the lane = quantity
+//   level  8: DPP row_mirror (l <-> 15 - l),       pair = n-tile 0 / 1                           -> bit 3 = j
+//   level  4: DPP row_half_mirror (l <-> 7 - l),   pair = channel pair kp 0 / 1                  -> bit 2 = kp
+//   level  2: DPP quad_perm [2,3,0,1],             pair = channels e / e + 4                      -> bit 1
+//   level  1: DPP quad_perm [1,0,3,2],             pair = channels e / e + 2                      -> bit 0
+// leaving two values (channels c, c + 1) per lane: one 8-byte store into stats[row][quantity][channel].
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <typename T, int BN>
+__device__ __forceinline__ void d_epilogue_stats(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const int (&mpix)[2],
+                                                 const size_t (&ooff)[2], int ch0, int lane, int row) {
+    constexpr int TN = BN / 64;
+    static_assert(TN == 2, "two n-tiles per wave");
+    float sq[2][TN][2][8];                                  // [quantity][j][kp][e]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sq[a][j][kp][e] = 0.f;
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float live = mpix[i] < 0 ? 0.f : 1.f;        // tile padding: the lane computed a duplicate of pixel 0, counts for nothing
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * kp + e]), __float_as_uint(acc[i][j][8 * kp + 4 + e]), false, false);
+                    w[e] = __uint_as_float(sw[0]);
+                    w[4 + e] = __uint_as_float(sw[1]);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
+                    const float r0 = HTraits<T>::to_f32((unsigned short)(o[e] & 0xffffu)) * live;
+                    const float r1 = HTraits<T>::to_f32((unsigned short)(o[e] >> 16)) * live;
+                    sq[0][j][kp][2 * e] += r0;
+                    sq[0][j][kp][2 * e + 1] += r1;
+                    sq[1][j][kp][2 * e] = __builtin_fmaf(r0, r0, sq[1][j][kp][2 * e]);
+                    sq[1][j][kp][2 * e + 1] = __builtin_fmaf(r1, r1, sq[1][j][kp][2 * e + 1]);
+                }
+                if (mpix[i] >= 0 && ch0 + j * 64 + kp * 16 < p.Cout) *reinterpret_cast<u32x4*>(yo + ooff[i] + j * 64 + kp * 16) = o;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // level 16
+    float l8[TN][2][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq[0][j][kp][e]), __float_as_uint(sq[1][j][kp][e]), false, false);
+                l8[j][kp][e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float l4[2][8];
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t0 = l8[0][kp][e] + dpp_f<0x140>(l8[0][kp][e]);       // row_mirror
+            const float t1 = l8[1][kp][e] + dpp_f<0x140>(l8[1][kp][e]);
+            l4[kp][e] = b3 ? t1 : t0;
+        }
+    float l2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t0 = l4[0][e] + dpp_f<0x141>(l4[0][e]);                   // row_half_mirror
+        const float t1 = l4[1][e] + dpp_f<0x141>(l4[1][e]);
+        l2[e] = b2 ? t1 : t0;
+    }
+    float l1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t0 = l2[e] + dpp_f<0x4E>(l2[e]);                          // quad_perm [2,3,0,1]
+        const float t1 = l2[e + 4] + dpp_f<0x4E>(l2[e + 4]);
+        l1[e] = b1 ? t1 : t0;
+    }
+    float l0[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float t0 = l1[e] + dpp_f<0xB1>(l1[e]);                          // quad_perm [1,0,3,2]
+        const float t1 = l1[e + 2] + dpp_f<0xB1>(l1[e + 2]);
+        l0[e] = b0 ? t1 : t0;
+    }
+    const int qty = (lane >> 4) & 1;
+    const int ch = ch0 + (b3 ? 64 : 0) + (b2 ? 16 : 0) + (b1 ? 4 : 0) + (b0 ? 2 : 0);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 out = {l0[0], l0[1]};
+    *reinterpret_cast<f32x2*>(p.stats + ((size_t)row * 2 + qty) * p.stats_ld + ch) = out;      // stats_ld covers the padded channel tiles
+}
+
 template <typename T, int BN, int PROBE = 0>
 __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     constexpr int TN = BN / 64;
@@ -1201,8 +1314,12 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     // stores every add waited for the stores before it (s_waitcnt vmcnt(0): one in-order counter, and the rows were requested
     // in another basic block) — ~500 cycles per store group on the 23 residual layers.
     bool saw_nan = false;
+    if (p.stats != nullptr) {                                         // train-mode forward: raw z + BatchNorm partial sums
+        d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+    } else {
     YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
                                              : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
+    }
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
 #ifdef H16_STAMPS
     {
@@ -1444,8 +1561,12 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
         }
     }
     bool saw_nan = false;
+    if (p.stats != nullptr) {                                         // train-mode forward: raw z + BatchNorm partial sums
+        d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+    } else {
     YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
                                              : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
+    }
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
 }
 
@@ -2140,6 +2261,7 @@ int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, c
     if (cout % 32) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2 (16-bit): cout %d must be a multiple of 32", cout);
     if ((dz_ld & 7) || (dz_off & 7)) return fail(YOLO_ERR_ARG, "dgrad_s2 (16-bit): dz_ld/dz_off must be multiples of 8");
     ConvHArgs a;
+    a.stats = nullptr; a.stats_ld = 0;
     a.x = (const unsigned short*)dz; a.scale = nullptr; a.shift = nullptr;
     a.res = (const unsigned short*)residual; a.y = dx; a.nan_flag = nullptr;
     a.Cin = cout; a.Cout = cin;
@@ -2172,12 +2294,30 @@ static int dispatch_h(ConvHArgs& a, int ks, int stride, int bn, hipStream_t s) {
 
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s) {
+    return conv_h16_launch_stats(d, x, wf, scale, shift, residual, y, nan_flag, nullptr, nullptr, nullptr, s);
+}
+
+// stats != nullptr: the launch must be one of the DMA kernels (conv3_dma_h16 / conv1_dma_h16) with an identity epilogue; it
+// also writes per-wave BatchNorm partial sums. dry (rows_ld != nullptr with x == nullptr): no launch, rows_ld[0..1] = the
+// number of partial rows and their channel stride, or 0 rows when this convolution has no fused-statistics kernel.
+int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
+                          const void* residual, void* y, int32_t* nan_flag, float* stats, int* rows_ld, const size_t* stats_bytes,
+                          hipStream_t s) {
+    const bool dry = rows_ld != nullptr && x == nullptr;
+    if (rows_ld) { rows_ld[0] = 0; rows_ld[1] = 0; }
     if (d->cin % 32) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): cin %d must be a multiple of 32", d->cin);
     if (d->ksize == 1 && d->stride != 1) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): strided 1x1");
     if ((d->x_ld & 7) || (d->x_off & 7)) return fail(YOLO_ERR_ARG, "conv (16-bit): x_ld/x_off must be multiples of 8");
     ConvHArgs a;
     a.x = (const unsigned short*)x; a.wf = (const unsigned short*)wf; a.scale = scale; a.shift = shift;
     a.res = (const unsigned short*)residual; a.y = y; a.nan_flag = nan_flag;
+    a.stats = stats; a.stats_ld = round_up(d->cout, 128);
+    const bool want_stats = stats != nullptr || dry;
+    // the DMA kernels request their scale / shift table in the prologue whatever the epilogue does with it: in statistics mode
+    // (identity epilogue, table unused) hand them readable memory - the statistics buffer itself (>= cout floats)
+    if (stats != nullptr) { a.scale = stats; a.shift = stats; }
+    if (want_stats && (d->act != YOLO_ACT_NONE || d->out_mode != YOLO_OUT_NHWC || (d->flags & YOLO_FLAG_RESIDUAL)))
+        return dry ? YOLO_OK : fail(YOLO_ERR_ARG, "conv (16-bit): statistics need the identity epilogue (raw convolution output)");
     a.Cin = d->cin; a.Cout = d->cout;
     a.x_ld = d->x_ld; a.x_off = d->x_off; a.y_ld = d->y_ld; a.y_off = d->y_off; a.r_ld = d->r_ld; a.r_off = d->r_off;
     const int pad = d->ksize / 2;
@@ -2210,9 +2350,16 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
         a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
         a.nc5 = 1;
         a.tiles_w = 1; a.first_wave = 0; a.stagger = 0; a.bufmask = 1; a.patch_cap = 128; a.mtab_off = 0;
+        if (want_stats) {
+            const int rows = 2 * ceil_div(a.W, 128);
+            if (rows_ld) { rows_ld[0] = rows; rows_ld[1] = a.stats_ld; }
+            if (dry) return YOLO_OK;
+            if (stats_bytes && *stats_bytes < (size_t)rows * 2 * a.stats_ld * sizeof(float)) return fail(YOLO_ERR_WORKSPACE, "conv statistics: buffer too small");
+        }
         if (d->dtype == YOLO_BF16) return launch_dma1<__bf16>(a, s);
         return launch_dma1<_Float16>(a, s);
     }
+    if (want_stats && !use_dma) return dry ? YOLO_OK : fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): no fused-statistics kernel for this convolution");
     if (d->ksize == 1) {
         a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = 128; a.PC = 128;
     } else {
@@ -2228,6 +2375,12 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
         a.KT = a.nchunks * 9;
         a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
         a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
+        if (want_stats) {
+            const int rows = 2 * a.tiles_w * ceil_div(a.rows_total, a.TH);
+            if (rows_ld) { rows_ld[0] = rows; rows_ld[1] = a.stats_ld; }
+            if (dry) return YOLO_OK;
+            if (stats_bytes && *stats_bytes < (size_t)rows * 2 * a.stats_ld * sizeof(float)) return fail(YOLO_ERR_WORKSPACE, "conv statistics: buffer too small");
+        }
         if (d->dtype == YOLO_BF16) return launch_dma<__bf16>(a, s);
         return launch_dma<_Float16>(a, s);
     }

@@ -49,6 +49,9 @@ _WGRAD_OVERLAP = os.environ.get("YOLO_WGRAD_OVERLAP", "1") != "0"      # A/B swi
 # Launch tables (tape.py): the whole-network forward / backward record their ~900 launches once per plan and replay them
 # through ONE C call (yolo_train_fwd_batch / yolo_train_bwd_batch). YOLO_TRAIN_TAPE=0 keeps the per-launch path (A/B).
 _TAPE = os.environ.get("YOLO_TRAIN_TAPE", "1") != "0"
+# BatchNorm batch statistics from the epilogue of the producing convolution (16-bit LDS-DMA kernels) instead of a separate pass
+# over z. YOLO_BN_FUSED_STATS=0 keeps the separate pass (A/B).
+_FUSED_STATS = os.environ.get("YOLO_BN_FUSED_STATS", "1") != "0"
 
 
 class TrainPlan:
@@ -67,7 +70,8 @@ class TrainPlan:
         self.stem = (dtype != "fp32" and op0 is not None and op0["x"].buf == prog.input.buf and
                      bool(L.lib().yolo_stem_supported(op0["block"].conv.in_channels, op0["block"].conv.out_channels, op0["k"], op0["s"])))
         self.z, self.stats = [], []
-        max_bn, max_wg = 256, 256
+        self.fused_stats = []             # per op: (rows, ld) of the partial sums its convolution's epilogue writes, or None
+        max_bn, max_wg, max_st = 256, 256, 0
         lib = L.lib()
         for op in prog.ops:
             blk, cv = op["block"], op["block"].conv
@@ -75,17 +79,27 @@ class TrainPlan:
             if blk.batch_norm_act and m <= 1:                   # nn.BatchNorm2d in train mode refuses this too
                 raise ValueError("Expected more than 1 value per channel when training, got input size "
                                  f"torch.Size([{self.B}, {cv.out_channels}, {op['Ho']}, {op['Wo']}])")
+            fs = None
             if blk.batch_norm_act:
                 self.z.append(torch.empty(m * cv.out_channels, **act))
                 self.stats.append(torch.empty(4, cv.out_channels, **f32))        # mean, invstd, scale, shift
                 max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, cv.out_channels))
+                if _FUSED_STATS and dtype != "fp32":
+                    d = _desc(self.B, op["x"], cv.in_channels, cv.out_channels, op["k"], op["s"], cv.out_channels, 0, dtype=self.code)
+                    ld = C.c_int(0)
+                    rows = lib.yolo_conv_stats_rows(d, C.byref(ld))
+                    if rows > 0:
+                        fs = (rows, ld.value)
+                        max_st = max(max_st, rows * 2 * ld.value * 4)
             else:
                 self.z.append(None)
                 self.stats.append(None)
                 max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, (cv.out_channels + 31) // 32 * 32))
+            self.fused_stats.append(fs)
             max_wg = max(max_wg, lib.yolo_wgrad_workspace_bytes(self.B, op["x"].H, op["x"].W, cv.in_channels, cv.out_channels,
                                                                  op["k"], op["s"], self.code))
         self.bn_ws = torch.empty(max_bn, dtype=torch.uint8, device=device)
+        self.st_ws = torch.empty(max(max_st, 16), dtype=torch.uint8, device=device)
         self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.blocks = [op["block"] for op in prog.ops]
@@ -167,9 +181,14 @@ def _forward_launches(lib, state, plan: TrainPlan, x, xin, preds, stream):
                                       out.data_ptr(), plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(head)")
             continue
         z = plan.z[i]
+        fs = plan.fused_stats[i] if not (i == 0 and plan.stem) else None
         if i == 0 and plan.stem:
             L.check(lib.yolo_stem_fwd(xin.data_ptr(), pk.stem_w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), z.data_ptr(), B,
                                       xv.H, xv.W, cout, cout, 0, L.ACT_NONE, code, plan.nan_flag.data_ptr(), stream), "yolo_stem_fwd(raw)")
+        elif fs is not None:              # raw conv + the BatchNorm partial sums of z from its epilogue: no statistics pass over z
+            d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0, dtype=code)
+            L.check(lib.yolo_conv_fwd_stats(d, plan.view_ptr(xv), pk.w.data_ptr(), z.data_ptr(), plan.st_ws.data_ptr(), plan.st_ws.numel(),
+                                            stream), "yolo_conv_fwd_stats")
         else:
             d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0, dtype=code)
             L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
@@ -179,10 +198,16 @@ def _forward_launches(lib, state, plan: TrainPlan, x, xin, preds, stream):
         m = B * op["Ho"] * op["Wo"]
         track = bn.track_running_stats and bn.running_mean is not None
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
-        L.check(lib.yolo_bn_stats(z.data_ptr(), m, cout, cout, 0, bn.weight.data_ptr(), bn.bias.data_ptr(), mom, float(bn.eps),
-                                  bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
-                                  st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), code,
-                                  plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
+        if fs is not None:
+            L.check(lib.yolo_bn_stats_from_partials(plan.st_ws.data_ptr(), fs[0], fs[1], m, cout, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                    mom, float(bn.eps), bn.running_mean.data_ptr() if track else 0,
+                                                    bn.running_var.data_ptr() if track else 0, st[0].data_ptr(), st[1].data_ptr(),
+                                                    st[2].data_ptr(), st[3].data_ptr(), stream), "yolo_bn_stats_from_partials")
+        else:
+            L.check(lib.yolo_bn_stats(z.data_ptr(), m, cout, cout, 0, bn.weight.data_ptr(), bn.bias.data_ptr(), mom, float(bn.eps),
+                                      bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                                      st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), code,
+                                      plan.bn_ws.data_ptr(), plan.bn_ws.numel(), stream), "yolo_bn_stats")
         if track:
             tracked.append(bn.num_batches_tracked)
             stats_written += [bn.running_mean, bn.running_var]
