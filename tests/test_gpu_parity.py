@@ -1551,6 +1551,79 @@ def test_dma_conv_kernels_edge_shapes(yt, case, dtype):
     keep[y_off:y_off + cout] = False
     assert torch.equal(got[..., keep], y0[..., keep])                           # neighbouring channels of the buffer untouched
 
+RS_CASES = [
+    # (B, H, cin, cout, residual, act, upsample, x_ld, x_off, y_ld, y_off): conv1_rs_f32 (fp32 1x1, weights in registers)
+    (2, 13, 256, 128, False, 1, False, 256, 0, 128, 0),        # 338 pixels: 11 tiles, the last one ragged; every workgroup gets <= 1 tile
+    (1, 52, 256, 128, False, 2, False, 256, 0, 128, 0),        # 85 tiles over 85 workgroups... one tile each, Mish
+    (8, 52, 256, 128, False, 1, False, 256, 0, 128, 0),        # 676 tiles on 256 workgroups: the ring wraps, 2-3 tiles per workgroup
+    (16, 52, 256, 128, True, 1, False, 256, 0, 128, 0),        # 1352 tiles: the size from which the heuristic picks this kernel
+    (3, 26, 384, 128, False, 1, False, 512, 64, 768, 256),     # K = 384: reads a slice of a concat buffer, writes into one
+    (4, 26, 512, 256, True, 0, False, 512, 0, 256, 0),         # K = 512 (2-slot ring), two channel groups, identity epilogue + residual
+    (2, 13, 256, 128, False, 1, True, 256, 0, 384, 128),       # the 1x1 in front of nn.Upsample: 2x store into the concat buffer
+    (5, 26, 512, 384, False, 1, False, 512, 0, 384, 0),        # three channel groups: 85 workgroups per group
+]
+
+
+@pytest.mark.parametrize("case", RS_CASES)
+def test_fp32_1x1_register_stationary_kernel(yt, case):
+    """conv1_rs_f32 through the C-ABI with `tile = 12` (and the default tile, which must pick it): ragged last tile, several tiles
+    per persistent workgroup, K = 256 / 384 / 512, channel groups, ld / off views of concat buffers, the 2x-upsampling store,
+    residual accumulate, every activation. Reference: fp64 convolution of the same operands (tolerance = fp32 accumulation)."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, cin, cout, residual, act, upsample, x_ld, x_off, y_ld, y_off = case
+    g = torch.Generator().manual_seed(500 + cin + cout + H + B)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    x = torch.randn((B, H, H, x_ld), generator=g)
+    w = torch.randn((cout, cin, 1, 1), generator=g) * (1.0 / cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    Ho = 2 * H if upsample else H
+    y0 = torch.randn((B, Ho, Ho, y_ld), generator=g)
+    r = torch.randn((B, H, H, cout), generator=g) if residual else None
+    xd, sd, shd, wd = x.to(dev), scale.to(dev), shift.to(dev), w.to(dev)
+    rd = r.to(dev) if residual else None
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, 1, L.F32), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, 1, L.F32, st))
+    xin = x[..., x_off:x_off + cin].double().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.1) if act == 1 else (F.mish(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + r.double()
+    if upsample:
+        ref = ref.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    outs = []
+    for tile in (12, 0, 4):                                      # explicit, heuristic (must be the same kernel), round 2's kernel
+        yd = y0.clone().to(dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=1, stride=1, x_ld=x_ld, x_off=x_off, y_ld=y_ld, y_off=y_off, r_ld=cout,
+                       r_off=0, act=act, out_mode=L.OUT_UPSAMPLE2X if upsample else L.OUT_NHWC, dtype=L.F32,
+                       flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
+        L.check(lib.yolo_conv_fwd(d, xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                  yd.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        got = yd.cpu()
+        err = float((got[..., y_off:y_off + cout].double() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-6, (tile, err)
+        keep = torch.ones(y_ld, dtype=torch.bool)
+        keep[y_off:y_off + cout] = False
+        assert torch.equal(got[..., keep], y0[..., keep])           # neighbouring channels of the buffer untouched
+        outs.append(got)
+    # tile 0 = the heuristic: this kernel from ~4 tiles per persistent workgroup on, the register-staged one below that
+    units = -(-(B * H * H) // 32) * (cout // 128)
+    assert torch.equal(outs[1], outs[0] if (units >= 4 * 256 and cin <= 384) else outs[2])
+    # a NaN in the input reaches the flag
+    xn = xd.clone()
+    xn[0, 0, 0, x_off] = float("nan")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    d.tile = 12
+    L.check(lib.yolo_conv_fwd(d, xn.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                              yd.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+    torch.cuda.synchronize()
+    assert int(flag.item()) & 2
+
+
 FUSED_STATS_CASES = [  # B, H, cin, cout, k: 3x3 / 1x1 LDS-DMA kernels; ragged and image-straddling tiles, channel tiles with padding
     (2, 13, 64, 128, 3), (3, 7, 96, 72, 3), (1, 52, 128, 256, 3), (4, 26, 128, 136, 3), (2, 13, 256, 128, 1), (1, 19, 128, 200, 1),
     (3, 5, 384, 128, 1)]

@@ -192,6 +192,10 @@ int v2_blocks(const yolo_conv_desc* d, int bn);          // grid size the patch 
 int v2_pack(const float* w_oihw, float* wf, int cout, int cin, int ks, hipStream_t s);
 int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, const float* scale, const float* shift,
                    const void* residual, void* y, int32_t* nan_flag, int bn, bool single_buffer, hipStream_t s);
+// conv1_rs_f32.hip (fp32 1x1, weights stationary in registers, persistent workgroups)
+bool conv1_rs_eligible(const yolo_conv_desc* d, const void* residual);
+int conv1_rs_launch(const yolo_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                    void* y, int32_t* nan_flag, hipStream_t s);
 // conv_h16.hip (bf16 / fp16 patch kernel)
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);

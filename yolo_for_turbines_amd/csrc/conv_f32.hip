@@ -341,6 +341,10 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     a.nc5 = d->out_mode == YOLO_OUT_HEAD ? d->cout / 3 : 1;
     a.tiles_n = 0;
     const bool smallc = a.Cin == 4;
+    // 1x1 with 256 / 384 / 512 input channels and a multiple of 128 output channels: weights stationary in registers (tile 0 =
+    // heuristic, or tile 12 explicitly; tiles 1-4 keep the register-staged kernel for A/B)
+    if ((d->tile == 0 || d->tile == 12) && conv1_rs_eligible(d, residual)) return conv1_rs_launch(d, x, w, scale, shift, residual, y, nan_flag, s);
+    if (d->tile == 12) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 12 needs a 1x1 with 256 / 384 / 512 input channels and cout %% 128 == 0");
     const int t = d->tile ? d->tile : pick_tile(d);
     if (t >= 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile ids from 8 up are 16-bit kernels (conv3_dma_h16)");
     if (t >= 5) {
