@@ -292,3 +292,19 @@ def test_head_bias_changed_alone_is_seen_by_the_next_train_forward(yt, autocast)
         e1 = m(x)
     assert float((e1[0] - e0[0] + 1.0).abs().max()) < 1e-5
     assert torch.equal(e1[1], e0[1])
+
+
+def test_rccl_all_reduce_inside_a_graph_capture_one_rank():
+    """RCCL collectives inside a HIP-graph capture (opt-in: GraphedTrainStep(allow_data_parallel=True)): with a 1-rank RCCL
+    group in a child process, replays of the captured data-parallel step (synchronous bucket all-reduces on the capturing
+    stream, communicator warmed up eagerly, thread-local capture errors) equal eager data-parallel steps bit for bit. Run
+    ONCE; the multi-rank case needs the driver's 8-GPU node."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YOLO_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_graph_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "DP_GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])

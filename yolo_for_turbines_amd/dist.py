@@ -189,7 +189,13 @@ class GradBuckets:
         b["pending"] = 0
         if self.dist is not None:
             op = self.dist.ReduceOp.AVG if self.use_avg else self.dist.ReduceOp.SUM
-            b["work"] = self.dist.all_reduce(b["buf"], op=op, async_op=True)
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # inside a HIP-graph capture: a synchronous collective (the process group joins its work back into the
+                # capturing stream before returning), no work handle that would outlive the capture
+                self.dist.all_reduce(b["buf"], op=op, async_op=False)
+                b["work"] = None
+            else:
+                b["work"] = self.dist.all_reduce(b["buf"], op=op, async_op=True)
 
     def complete_all(self):
         """A replayed launch table has written every gradient: nothing is pending (buckets without a collective)."""

@@ -9,6 +9,8 @@ so ``torch.cuda.graph`` can record the whole step into ONE HIP graph. Static sha
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .loss import FusedYOLOLoss
@@ -25,12 +27,16 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, scaled_anchors, x, targets, autocast_dtype=None, loss_fn=None, warmup=3,
-                 zero_grad=True):
+                 zero_grad=True, allow_data_parallel=None):
         if not x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors (no CPU fallback)")
-        if getattr(model._engine, "ddp", None) is not None and model._engine.ddp[0] is not None:
-            raise NotImplementedError("GraphedTrainStep does not capture the data-parallel gradient all-reduce (RCCL inside a HIP "
-                                      "graph capture is not validated here); replay per rank is single-GPU only")
+        if allow_data_parallel is None:
+            allow_data_parallel = os.environ.get("YOLO_DP_GRAPH", "0") == "1"
+        self._dp = getattr(model._engine, "ddp", None) is not None and model._engine.ddp[0] is not None
+        if self._dp and not allow_data_parallel:
+            raise NotImplementedError("GraphedTrainStep does not capture the data-parallel gradient all-reduce by default (RCCL inside a "
+                                      "HIP graph capture has only been exercised with a 1-rank group here: DESIGN.md); pass "
+                                      "allow_data_parallel=True / YOLO_DP_GRAPH=1 to capture it, or replay per rank on one GPU")
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn if loss_fn is not None else FusedYOLOLoss()
         self.autocast_dtype = autocast_dtype
@@ -63,7 +69,11 @@ class GraphedTrainStep:
             self._baked = None if hasattr(self.opt, "sync_hyper") else self._hyper_snapshot()
             if self.zero_grad:
                 self.opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self.graph):
+            # data parallel (opt-in): the warm-up steps above have created the communicator and run every bucket's collective
+            # once eagerly; inside the capture the buckets issue synchronous all-reduces on the capturing stream
+            # (dist.GradBuckets.fire), and capture errors stay local to this thread
+            kw = {"capture_error_mode": "thread_local"} if self._dp else {}
+            with torch.cuda.graph(self.graph, **kw):
                 self.loss = self._step_body(zero=False)
         finally:
             model._engine.nan_check = self._nan_check
