@@ -1624,6 +1624,63 @@ def test_fp32_1x1_register_stationary_kernel(yt, case):
     assert int(flag.item()) & 2
 
 
+S2_CASES = [  # (B, H, cin, cout, residual, act, y_ld, y_off): 3x3 stride 2 on conv1_dma_h16 with gathered rows (tile 13)
+    (2, 26, 64, 128, False, 1, 128, 0),          # KT = 18; 338 output pixels: three tiles, the last ragged
+    (1, 52, 128, 256, False, 2, 256, 0),         # two n tiles
+    (3, 10, 256, 136, False, 1, 136, 0),         # cout not a multiple of 128; 5x5 outputs: tiles straddle rows and images
+    (2, 20, 96, 128, True, 0, 192, 64),          # three chunks (odd), residual accumulate into a slice of a wider buffer
+    (1, 104, 128, 256, False, 1, 256, 0),        # 2,704 output pixels
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", S2_CASES)
+def test_stride2_conv_as_gathered_gemm(yt, case, dtype):
+    """The stride-2 3x3 blocks on conv1_dma_h16 with gathered activation rows (tile 13, and the default tile, which must pick
+    it): image borders (top row / left column taps read the zero page), ragged and image-straddling pixel tiles, channel
+    tiles with padding, residual + ld / off views. Reference: fp64 convolution of the same rounded operands."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, cin, cout, residual, act, y_ld, y_off = case
+    code, tdt, tol = {"bf16": (L.BF16, torch.bfloat16, 1e-2), "fp16": (L.F16, torch.float16, 2e-3)}[dtype]
+    g = torch.Generator().manual_seed(900 + cin + cout + H)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    Ho = H // 2
+    x = torch.randn((B, H, H, cin), generator=g).to(tdt)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (cin * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    y0 = torch.randn((B, Ho, Ho, y_ld), generator=g).to(tdt)
+    r = torch.randn((B, Ho, Ho, cout), generator=g).to(tdt) if residual else None
+    xd, sd, shd, wd = x.to(dev), scale.to(dev), shift.to(dev), w.to(dev)
+    rd = r.to(dev) if residual else None
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, 3, code), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, 3, code, st))
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(tdt).double(), stride=2, padding=1)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.1) if act == 1 else (F.mish(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + r.double()
+    outs = []
+    for tile in (13, 0, 6):                                     # explicit, heuristic (the same kernel), round 2's kernel
+        yd = y0.clone().to(dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=3, stride=2, x_ld=cin, x_off=0, y_ld=y_ld, y_off=y_off, r_ld=cout, r_off=0,
+                       act=act, out_mode=L.OUT_NHWC, dtype=code, flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
+        L.check(lib.yolo_conv_fwd(d, xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                  yd.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        got = yd.cpu()
+        err = float((got[..., y_off:y_off + cout].double() - ref).abs().max() / ref.abs().max())
+        assert err <= tol, (tile, err)
+        keep = torch.ones(y_ld, dtype=torch.bool)
+        keep[y_off:y_off + cout] = False
+        assert torch.equal(got[..., keep], y0[..., keep])
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])
+
+
 FUSED_STATS_CASES = [  # B, H, cin, cout, k: 3x3 / 1x1 LDS-DMA kernels; ragged and image-straddling tiles, channel tiles with padding
     (2, 13, 64, 128, 3), (3, 7, 96, 72, 3), (1, 52, 128, 256, 3), (4, 26, 128, 136, 3), (2, 13, 256, 128, 1), (1, 19, 128, 200, 1),
     (3, 5, 384, 128, 1)]

@@ -1356,12 +1356,27 @@ constexpr int E_A_BYTES = 128 * 64;              // activation slab of one step
 constexpr int E_W_BYTES = 4 * 2048;              // weight slab of one step (BN = 128)
 constexpr int E_SLOT_BYTES = E_A_BYTES + E_W_BYTES;
 
+// GATH = 1 (3x3 stride 2 as a GEMM with gathered rows, see conv1_dma_h16): source of this lane's activation granule for the
+// K step (chunk, tap): the pixel's base + the tap's offset, or the zero page where the tap falls outside the image (only the
+// top row / left column can: H and W are even)
+struct EGather {
+    const unsigned short* zp;
+    int vmask[2];                    // per pixel row of this lane: bit 0 = output row > 0, bit 1 = output column > 0
+    int tap, chunk;                  // of the NEXT step to request
+};
+__device__ __forceinline__ const unsigned short* e_gsrc(const ConvHArgs& p, const unsigned short* base, int vmask, const EGather& g) {
+    const int kh = (g.tap * 11) >> 5, kw = g.tap - 3 * kh;
+    const int off = ((kh - 1) * p.Win + (kw - 1)) * p.x_ld + g.chunk * 32;
+    const bool ok = (kh > 0 || (vmask & 1)) && (kw > 0 || (vmask & 2));
+    return ok ? base + off : g.zp;
+}
+
 // LU = -1: a step of the steady loop (requests step t + E_P); LU = 0..3: the last four steps (nothing left to request)
-template <typename T, int LU>
+template <typename T, int LU, int GATH = 0>
 __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const unsigned short* const (&asrc)[2], const unsigned short* wsrc,
                                        int t, int& slot_w, int& slot_r, u32x4 (&af)[2][2], u32x4 (&bf)[2][2], f32x16 (&acc)[2][2],
                                        int wave, int lane, int wn, const int (&aoff)[2][2], const DRes& rs, u32x4 (&rr)[2][2][2],
-                                       const float* ss_src, int ss_slot) {
+                                       const float* ss_src, int ss_slot, EGather& eg) {
     typedef typename HTraits<T>::vec vec;
 #define E_MFMA(i, j, s) acc[i][j] = HTraits<T>::mfma(__builtin_bit_cast(vec, bf[s][j]), __builtin_bit_cast(vec, af[i][s]), acc[i][j])
     constexpr bool fetch = LU < 0;
@@ -1398,7 +1413,7 @@ __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const uns
     bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(0, 0, 1);
-    if (fetch) glds16(asrc[0] + (size_t)(t + E_P) * 32, dst);
+    if (fetch) glds16(GATH ? e_gsrc(p, asrc[0], eg.vmask[0], eg) : asrc[0] + (size_t)(t + E_P) * 32, dst);
     bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
     bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
     __builtin_amdgcn_sched_barrier(0);
@@ -1414,7 +1429,11 @@ __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const uns
     }
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(0, 1, 1);
-    if (fetch) glds16(asrc[1] + (size_t)(t + E_P) * 32, dst + 1024);
+    if (fetch) glds16(GATH ? e_gsrc(p, asrc[1], eg.vmask[1], eg) : asrc[1] + (size_t)(t + E_P) * 32, dst + 1024);
+    if (GATH && fetch) {                                      // K order of the fragment stream: chunk-major, the 9 taps inside
+        eg.tap = eg.tap == 8 ? 0 : eg.tap + 1;
+        eg.chunk += eg.tap == 0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(1, 1, 1);
 #undef E_MFMA
@@ -1435,7 +1454,13 @@ __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const uns
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int BN>
+// GATH = 1: the same kernel as a GEMM with GATHERED activation rows = the 3x3 STRIDE-2 blocks (model.py:20-45: the five
+// downsampling layers). z[r, c] = sum over (tap, ci) of x[2r + kh - 1, 2c + kw - 1, ci] W[co, ci, kh, kw] is a product with
+// K = 9 Cin whose A row for output pixel m and K step (chunk, tap) is 32 consecutive channels of ONE input pixel: per lane a
+// base pointer (pixel (2r, 2c)) plus a wave-uniform offset per step, and the zero page for the taps that leave the image at the
+// top row / left column. The weights are the ordinary 3x3 fragment stream (chunk-major, taps inside). No patch, no halo
+// re-reads beyond L2: round 2's register-staged stride-2 kernel ran these layers at 81-113 us (450-630 TF).
+template <typename T, int BN, int GATH = 0>
 __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
     static_assert(BN == 128, "4 waves x (2 x 2) tiles of 32 x 32");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1457,21 +1482,38 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
     const unsigned short* wsrc = p.wf + (size_t)(n_tile * (BN / 32) + wave) * p.KT * 1024 + lane * 8;
     // this lane's two activation rows (DMA rounds 2 wave, 2 wave + 1 of 16 pixels x 4 granules), clamped to the last pixel
     const unsigned short* asrc[2];
+    EGather eg;
+    eg.tap = 0; eg.chunk = 0; eg.vmask[0] = eg.vmask[1] = 3;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int px = 16 * (2 * wave + r) + (lane >> 2);
         int m = sp * 128 + px;
         m = m < M ? m : M - 1;
         const int gs = (lane & 3) ^ ((px >> 2) & 3);
-        asrc[r] = p.x + (size_t)m * p.x_ld + p.x_off + gs * 8;
+        if (GATH) {                                                    // output pixel m = (img, orow, ocol) -> input pixel (2 orow, 2 ocol)
+            const int img = fdiv(m, p.mg_PC, p.PC), rem = m - img * p.PC;
+            const int orow = fdiv(rem, p.mg_TW, p.TW), ocol = rem - orow * p.TW;
+            eg.vmask[r] = (orow > 0 ? 1 : 0) | (ocol > 0 ? 2 : 0);
+            asrc[r] = p.x + ((size_t)(img * p.Hin + 2 * orow) * p.Win + 2 * ocol) * p.x_ld + p.x_off + gs * 8;
+        } else {
+            asrc[r] = p.x + (size_t)m * p.x_ld + p.x_off + gs * 8;
+        }
     }
+    eg.zp = reinterpret_cast<const unsigned short*>(g_zero_page);   // (any granule of the zero page is zeros)
 #pragma unroll
     for (int q = 0; q < E_P; ++q) {                                    // steps 0 .. 3, four requests each
         char* dst = ring + q * E_SLOT_BYTES + wave * 2048;
         glds16(wsrc + (size_t)q * 1024, dst + E_A_BYTES);
         glds16(wsrc + (size_t)q * 1024 + 512, dst + E_A_BYTES + 1024);
-        glds16(asrc[0] + (size_t)q * 32, dst);
-        glds16(asrc[1] + (size_t)q * 32, dst + 1024);
+        if (GATH) {
+            glds16(e_gsrc(p, asrc[0], eg.vmask[0], eg), dst);
+            glds16(e_gsrc(p, asrc[1], eg.vmask[1], eg), dst + 1024);
+            eg.tap = eg.tap == 8 ? 0 : eg.tap + 1;
+            eg.chunk += eg.tap == 0;
+        } else {
+            glds16(asrc[0] + (size_t)q * 32, dst);
+            glds16(asrc[1] + (size_t)q * 32, dst + 1024);
+        }
     }
     // fragment rows: byte offsets of this lane's two pixels x two k16 halves inside an activation slab, output pixels
     int aoff[2][2], mpix[2];
@@ -1535,11 +1577,11 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
     int slot_w = E_P % E_SLOTS, slot_r = 1;
     int t = 0;
     for (; t + 4 < p.KT; ++t)
-        e_step<T, -1>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
-    e_step<T, 0>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
-    e_step<T, 1>(p, ring, asrc, wsrc, t + 1, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
-    e_step<T, 2>(p, ring, asrc, wsrc, t + 2, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
-    e_step<T, 3>(p, ring, asrc, wsrc, t + 3, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot);
+        e_step<T, -1, GATH>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot, eg);
+    e_step<T, 0, GATH>(p, ring, asrc, wsrc, t, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot, eg);
+    e_step<T, 1, GATH>(p, ring, asrc, wsrc, t + 1, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot, eg);
+    e_step<T, 2, GATH>(p, ring, asrc, wsrc, t + 2, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot, eg);
+    e_step<T, 3, GATH>(p, ring, asrc, wsrc, t + 3, slot_w, slot_r, af, bf, acc, wave, lane, wn, aoff, rs, rr, ss_src, ss_slot, eg);
     if (p.prio) __builtin_amdgcn_s_setprio(2);
 
     const float* sstab = reinterpret_cast<const float*>(ring + ss_slot * E_SLOT_BYTES);   // [BN] scale, [BN] shift
@@ -2204,7 +2246,7 @@ static int launch_dma(ConvHArgs& a, hipStream_t s) {
     return check_launch("conv3_dma_h16");
 }
 
-template <typename T>
+template <typename T, int GATH = 0>
 static int launch_dma1(ConvHArgs& a, hipStream_t s) {
     constexpr int BN = 128;
     a.tiles_n = ceil_div(a.Cout, BN);
@@ -2213,8 +2255,8 @@ static int launch_dma1(ConvHArgs& a, hipStream_t s) {
     a.prio = g_h_prio ? 1 : 0;
     const size_t lds = (size_t)E_SLOTS * E_SLOT_BYTES;      // 80 KiB: two blocks per CU
     static LdsOnce once;
-    if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&conv1_dma_h16<T, BN>), lds, "conv1_dma_h16")) return rc;
-    hipLaunchKernelGGL((conv1_dma_h16<T, BN>), dim3(a.nblocks), dim3(256), lds, s, a);
+    if (int rc = reserve_lds(once, reinterpret_cast<const void*>(&conv1_dma_h16<T, BN, GATH>), lds, "conv1_dma_h16")) return rc;
+    hipLaunchKernelGGL((conv1_dma_h16<T, BN, GATH>), dim3(a.nblocks), dim3(256), lds, s, a);
     return check_launch("conv1_dma_h16");
 }
 
@@ -2358,6 +2400,28 @@ int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf
         }
         if (d->dtype == YOLO_BF16) return launch_dma1<__bf16>(a, s);
         return launch_dma1<_Float16>(a, s);
+    }
+    // 3x3 stride 2 with >= 128 output channels: conv1_dma_h16 as a GEMM with gathered rows (tile 0 / 13; tiles 5, 6 keep conv_patch_h16)
+    static const bool no_s2_dma = getenv("YOLO_NO_S2_DMA") != nullptr;
+    const bool s2_ok = d->ksize == 3 && d->stride == 2 && d->cout >= 128 && d->cout % 8 == 0 && d->out_mode == YOLO_OUT_NHWC &&
+                       (d->y_ld & 7) == 0 && (d->y_off & 7) == 0 && (!residual || ((d->r_ld & 7) == 0 && (d->r_off & 7) == 0)) &&
+                       (long long)a.Ho * a.Wo < 0x7fffffffLL && d->cin * 9 / 32 >= 4;
+    if (d->tile == 13 && !s2_ok) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 13 needs 3x3 stride 2 with >= 128 output channels");
+    if (s2_ok && (d->tile == 13 || (d->tile == 0 && g_h_dma && !no_s2_dma))) {
+        a.H = 1; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = a.Wo; a.PC = a.Ho * a.Wo;      // TW / PC: divisors of the pixel index
+        a.nchunks = d->cin / 32;
+        a.KT = a.nchunks * 9;
+        a.act = d->act; a.out_mode = d->out_mode; a.flags = d->flags;
+        a.nc5 = 1;
+        a.tiles_w = 1; a.first_wave = 0; a.stagger = 0; a.bufmask = 1; a.patch_cap = 128; a.mtab_off = 0;
+        if (want_stats) {
+            const int rows = 2 * ceil_div(a.W, 128);
+            if (rows_ld) { rows_ld[0] = rows; rows_ld[1] = a.stats_ld; }
+            if (dry) return YOLO_OK;
+            if (stats_bytes && *stats_bytes < (size_t)rows * 2 * a.stats_ld * sizeof(float)) return fail(YOLO_ERR_WORKSPACE, "conv statistics: buffer too small");
+        }
+        if (d->dtype == YOLO_BF16) return launch_dma1<__bf16, 1>(a, s);
+        return launch_dma1<_Float16, 1>(a, s);
     }
     if (want_stats && !use_dma) return dry ? YOLO_OK : fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): no fused-statistics kernel for this convolution");
     if (d->ksize == 1) {
