@@ -1681,6 +1681,52 @@ def test_stride2_conv_as_gathered_gemm(yt, case, dtype):
     assert torch.equal(outs[0], outs[1])
 
 
+S2_DGRAD_CASES = [  # (B, Ho, cin, cout, residual, dz_ld, dx_ld, dx_off)
+    (2, 13, 32, 64, False, 64, 32, 0),           # the stem's successor: four classes in ONE n tile; 338 dz pixels, ragged last tile
+    (1, 26, 64, 128, True, 128, 64, 0),          # two n tiles, accumulate into the running gradient
+    (3, 5, 64, 128, True, 160, 96, 32),          # tiles straddle rows and images; dz / dx are slices of wider buffers
+    (2, 8, 32, 96, False, 96, 32, 0),            # three chunks
+    (1, 12, 128, 256, True, 256, 128, 0),        # > 64 channels: the four per-class launches (unchanged path)
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", S2_DGRAD_CASES)
+def test_stride2_input_gradient_kernels(yt, case, dtype):
+    """yolo_conv_dgrad_s2: dx of a 3x3 stride-2 convolution (model.py:17's conv in the five down-sampling blocks). For
+    <= 64 dx channels the four parity classes run as ONE gathered-row GEMM (conv1_dma_h16, gather mode 2); wider layers
+    keep one launch per class. Reference: fp64 conv_transpose2d of the same rounded operands; the last row / column of
+    dz (neighbours outside the image read the zero page), residual accumulate and ld / off views are covered."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, Ho, cin, cout, residual, dz_ld, dx_ld, dx_off = case
+    code, tdt, tol = {"bf16": (L.BF16, torch.bfloat16, 1e-2), "fp16": (L.F16, torch.float16, 2e-3)}[dtype]
+    g = torch.Generator().manual_seed(1300 + cin + cout + Ho)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    H = 2 * Ho
+    dz = torch.randn((B, Ho, Ho, dz_ld), generator=g).to(tdt)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (cout * 2.25)) ** 0.5
+    dx0 = torch.randn((B, H, H, dx_ld), generator=g).to(tdt)
+    wd = w.to(dev)
+    wp = torch.empty(lib.yolo_packed_dgrad_bytes(cout, cin, 3, 0, code), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights_dgrad(wd.data_ptr(), wp.data_ptr(), cout, cin, 3, 0, code, st))
+    ref = F.conv_transpose2d(dz[..., :cout].double().permute(0, 3, 1, 2), w.to(tdt).double(), stride=2, padding=1, output_padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + dx0[..., dx_off:dx_off + cin].double()
+    dzd, dxd = dz.to(dev), dx0.clone().to(dev)
+    rptr = dxd.data_ptr() if residual else 0
+    L.check(lib.yolo_conv_dgrad_s2(dzd.data_ptr(), dz_ld, 0, wp.data_ptr(), rptr, dx_ld, dx_off, dxd.data_ptr(), dx_ld, dx_off, B, Ho, Ho,
+                                   cin, cout, code, st), "yolo_conv_dgrad_s2")
+    torch.cuda.synchronize()
+    got = dxd.cpu()
+    err = float((got[..., dx_off:dx_off + cin].double() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err
+    keep = torch.ones(dx_ld, dtype=torch.bool)
+    keep[dx_off:dx_off + cin] = False
+    assert torch.equal(got[..., keep], dx0[..., keep])
+
+
 FUSED_STATS_CASES = [  # B, H, cin, cout, k: 3x3 / 1x1 LDS-DMA kernels; ragged and image-straddling tiles, channel tiles with padding
     (2, 13, 64, 128, 3), (3, 7, 96, 72, 3), (1, 52, 128, 256, 3), (4, 26, 128, 136, 3), (2, 13, 256, 128, 1), (1, 19, 128, 200, 1),
     (3, 5, 384, 128, 1)]

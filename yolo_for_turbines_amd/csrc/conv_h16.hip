@@ -1104,6 +1104,53 @@ __device__ __forceinline__ void d_epilogue_stats(const ConvHArgs& p, const f32x1
     *reinterpret_cast<f32x2*>(p.stats + ((size_t)row * 2 + qty) * p.stats_ld + ch) = out;      // stats_ld covers the padded channel tiles
 }
 
+// ---- epilogue of the FUSED stride-2 input gradient (conv1_dma_h16<GATH = 2>): the GEMM's output channel n = class * C + c
+// (class = (ph, pw) parity of the dx pixel inside the 2 x 2 block of dz pixel m, C = p.H channels of dx), identity epilogue,
+// optional accumulate into what is already there (p.res / r_ld / r_off address the same pixels of the running gradient).
+// Each lane holds 8 consecutive n per (j, kp): one class, 8 consecutive channels -> a 16-byte store at pixel (2 row + ph, 2 col + pw).
+template <typename T, int BN>
+__device__ __forceinline__ void d_epilogue_s2g(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const int (&mpix)[2], int ch0) {
+    constexpr int TN = BN / 64;
+    const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+    const int W2 = 2 * p.Win;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mpix[i] < 0 ? 0 : mpix[i];
+        const int img = fdiv(m, p.mg_PC, p.PC), rem = m - img * p.PC;
+        const int row = fdiv(rem, p.mg_TW, p.TW), col = rem - row * p.TW;
+        const size_t blk = (size_t)(img * 2 * p.Hin + 2 * row) * W2 + 2 * col;          // dx pixel (2 row, 2 col)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * kp + e]), __float_as_uint(acc[i][j][8 * kp + 4 + e]), false, false);
+                    w[e] = __uint_as_float(sw[0]);
+                    w[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int nb = ch0 + j * 64 + kp * 16;
+                const int cls = fdiv(nb, p.mg_H, p.H), c = nb - cls * p.H;
+                const size_t pix = blk + (size_t)(cls >> 1) * W2 + (cls & 1);
+                if (mpix[i] < 0 || nb >= p.Cout) continue;
+                if (has_res) {
+                    const u32x4 r4 = *reinterpret_cast<const u32x4*>(p.res + pix * p.r_ld + p.r_off + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w[2 * e] += HTraits<T>::to_f32((unsigned short)(r4[e] & 0xffffu));
+                        w[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(r4[e] >> 16));
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
+                *reinterpret_cast<u32x4*>(yo + pix * p.y_ld + p.y_off + c) = o;
+            }
+    }
+}
+
 template <typename T, int BN, int PROBE = 0>
 __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     constexpr int TN = BN / 64;
@@ -1364,11 +1411,24 @@ struct EGather {
     int vmask[2];                    // per pixel row of this lane: bit 0 = output row > 0, bit 1 = output column > 0
     int tap, chunk;                  // of the NEXT step to request
 };
+template <int GATH>
 __device__ __forceinline__ const unsigned short* e_gsrc(const ConvHArgs& p, const unsigned short* base, int vmask, const EGather& g) {
-    const int kh = (g.tap * 11) >> 5, kw = g.tap - 3 * kh;
-    const int off = ((kh - 1) * p.Win + (kw - 1)) * p.x_ld + g.chunk * 32;
-    const bool ok = (kh > 0 || (vmask & 1)) && (kw > 0 || (vmask & 2));
-    return ok ? base + off : g.zp;
+    if constexpr (GATH == 1) {                               // 3x3 stride 2 forward: tap (kh, kw) of the input window
+        const int kh = (g.tap * 11) >> 5, kw = g.tap - 3 * kh;
+        const int off = ((kh - 1) * p.Win + (kw - 1)) * p.x_ld + g.chunk * 32;
+        const bool ok = (kh > 0 || (vmask & 1)) && (kw > 0 || (vmask & 2));
+        return ok ? base + off : g.zp;
+    } else {                                                 // stride-2 input gradient: neighbour (dr, dc) of the dz pixel
+        const int dr = g.tap >> 1, dc = g.tap & 1;
+        const int off = (dr * p.Win + dc) * p.x_ld + g.chunk * 32;
+        const bool ok = (!dr || (vmask & 1)) && (!dc || (vmask & 2));
+        return ok ? base + off : g.zp;
+    }
+}
+template <int GATH> __device__ __forceinline__ void e_gnext(EGather& g) {
+    constexpr int last = GATH == 1 ? 8 : 3;
+    g.tap = g.tap == last ? 0 : g.tap + 1;
+    g.chunk += g.tap == 0;
 }
 
 // LU = -1: a step of the steady loop (requests step t + E_P); LU = 0..3: the last four steps (nothing left to request)
@@ -1413,7 +1473,10 @@ __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const uns
     bn[1][0] = *reinterpret_cast<const u32x4*>(wb + 1024);
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(0, 0, 1);
-    if (fetch) glds16(GATH ? e_gsrc(p, asrc[0], eg.vmask[0], eg) : asrc[0] + (size_t)(t + E_P) * 32, dst);
+    if (fetch) {
+        if constexpr (GATH != 0) glds16(e_gsrc<GATH>(p, asrc[0], eg.vmask[0], eg), dst);
+        else glds16(asrc[0] + (size_t)(t + E_P) * 32, dst);
+    }
     bn[0][1] = *reinterpret_cast<const u32x4*>(wb + 4096);
     bn[1][1] = *reinterpret_cast<const u32x4*>(wb + 4096 + 1024);
     __builtin_amdgcn_sched_barrier(0);
@@ -1429,10 +1492,13 @@ __device__ __forceinline__ void e_step(const ConvHArgs& p, char* ring, const uns
     }
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(0, 1, 1);
-    if (fetch) glds16(GATH ? e_gsrc(p, asrc[1], eg.vmask[1], eg) : asrc[1] + (size_t)(t + E_P) * 32, dst + 1024);
-    if (GATH && fetch) {                                      // K order of the fragment stream: chunk-major, the 9 taps inside
-        eg.tap = eg.tap == 8 ? 0 : eg.tap + 1;
-        eg.chunk += eg.tap == 0;
+    if (fetch) {
+        if constexpr (GATH != 0) {
+            glds16(e_gsrc<GATH>(p, asrc[1], eg.vmask[1], eg), dst + 1024);
+            e_gnext<GATH>(eg);                                // K order of the fragment stream: chunk-major, the taps inside
+        } else {
+            glds16(asrc[1] + (size_t)(t + E_P) * 32, dst + 1024);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     E_MFMA(1, 1, 1);
@@ -1490,11 +1556,16 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
         int m = sp * 128 + px;
         m = m < M ? m : M - 1;
         const int gs = (lane & 3) ^ ((px >> 2) & 3);
-        if (GATH) {                                                    // output pixel m = (img, orow, ocol) -> input pixel (2 orow, 2 ocol)
+        if constexpr (GATH == 1) {                                     // output pixel m = (img, orow, ocol) -> input pixel (2 orow, 2 ocol)
             const int img = fdiv(m, p.mg_PC, p.PC), rem = m - img * p.PC;
             const int orow = fdiv(rem, p.mg_TW, p.TW), ocol = rem - orow * p.TW;
             eg.vmask[r] = (orow > 0 ? 1 : 0) | (ocol > 0 ? 2 : 0);
             asrc[r] = p.x + ((size_t)(img * p.Hin + 2 * orow) * p.Win + 2 * ocol) * p.x_ld + p.x_off + gs * 8;
+        } else if constexpr (GATH == 2) {                              // dz pixel m = (img, row, col): neighbours below / right exist?
+            const int img = fdiv(m, p.mg_PC, p.PC), rem = m - img * p.PC;
+            const int row = fdiv(rem, p.mg_TW, p.TW), col = rem - row * p.TW;
+            eg.vmask[r] = (row < p.Hin - 1 ? 1 : 0) | (col < p.Win - 1 ? 2 : 0);
+            asrc[r] = p.x + (size_t)m * p.x_ld + p.x_off + gs * 8;
         } else {
             asrc[r] = p.x + (size_t)m * p.x_ld + p.x_off + gs * 8;
         }
@@ -1505,11 +1576,10 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
         char* dst = ring + q * E_SLOT_BYTES + wave * 2048;
         glds16(wsrc + (size_t)q * 1024, dst + E_A_BYTES);
         glds16(wsrc + (size_t)q * 1024 + 512, dst + E_A_BYTES + 1024);
-        if (GATH) {
-            glds16(e_gsrc(p, asrc[0], eg.vmask[0], eg), dst);
-            glds16(e_gsrc(p, asrc[1], eg.vmask[1], eg), dst + 1024);
-            eg.tap = eg.tap == 8 ? 0 : eg.tap + 1;
-            eg.chunk += eg.tap == 0;
+        if constexpr (GATH != 0) {
+            glds16(e_gsrc<GATH>(p, asrc[0], eg.vmask[0], eg), dst);
+            glds16(e_gsrc<GATH>(p, asrc[1], eg.vmask[1], eg), dst + 1024);
+            e_gnext<GATH>(eg);
         } else {
             glds16(asrc[0] + (size_t)q * 32, dst);
             glds16(asrc[1] + (size_t)q * 32, dst + 1024);
@@ -1528,7 +1598,7 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
     const bool has_res = p.flags & YOLO_FLAG_RESIDUAL;
     DRes rs;
     rs.ch0 = n_tile * BN + wn * 32 + 8 * fh;
-    rs.has_res = has_res;
+    rs.has_res = GATH == 2 ? false : has_res;                           // (GATH 2: the epilogue reads the running gradient itself)
     u32x4 rr[2][2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1603,11 +1673,15 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
         }
     }
     bool saw_nan = false;
+    if constexpr (GATH == 2) {                                        // stride-2 input gradient: the four parity classes of a 2 x 2 block
+        d_epilogue_s2g<T, BN>(p, acc, mpix, ch0);
+    } else {
     if (p.stats != nullptr) {                                         // train-mode forward: raw z + BatchNorm partial sums
         d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
     } else {
     YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
                                              : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
+    }
     }
     if (nan_chk && saw_nan) atomicOr(p.nan_flag, 2);
 }
@@ -2117,10 +2191,45 @@ __global__ void pack_dgrad_s2_cls_h16(const float* __restrict__ w, unsigned shor
     }
 }
 
+// ---- the same gradient as ONE launch for the layers with few dx channels (C = cin <= 64, multiple of 32): the four classes
+// are the column blocks of one GEMM over the dz pixels, K = 4 neighbours x cout, N = 4 classes x C:
+//   dx[n, 2r+ph, 2c+pw, :] = sum over neighbours (dr <= ph, dc <= pw) of dz[n, r+dr, c+dc, :] . W[:, :, ph+1-2dr, pw+1-2dc]
+// 7 of the 16 (neighbour, class) blocks are zeros (1.78 x the matrix work), which these layers can afford: the four tap-subset
+// launches each read all of dz and write a quarter of dx in half-line pieces, HBM-bound at 2.5 TB/s (4 x ~97 us for the
+// 64-channel layers); here dz is read once and dx written once in full 16-byte rows.
+static bool s2g_ok(int cout, int cin) {
+    static const bool off = getenv("YOLO_NO_S2G") != nullptr;
+    return !off && (cin == 32 || cin == 64) && cout % 32 == 0 && cout >= 32;
+}
+static size_t s2g_frag_elems(int cout, int cin) { return s2g_ok(cout, cin) ? (size_t)(4 * cin / 32) * (4 * cout / 32) * 1024 : 0; }
+
+// [n_tile32][kt][s][lane][e]: n = class * cin + c, kt = chunk * 4 + neighbour, k = dz channel chunk * 32 + s * 16 + 8 (lane >> 5) + e
+template <typename T>
+__global__ void pack_dgrad_s2g_h16(const float* __restrict__ w, unsigned short* __restrict__ wf, int cout, int cin, long long total) {
+    const int KT = 4 * (cout / 32);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const int s = (int)((i >> 9) & 1);
+        const long long rest = i >> 10;
+        const int kt = (int)(rest % KT);
+        const int nt = (int)(rest / KT);
+        const int n = nt * 32 + (lane & 31);
+        const int cls = n / cin, c = n - cls * cin;
+        const int ph = cls >> 1, pw = cls & 1;
+        const int chunk = kt >> 2, nb = kt & 3;
+        const int dr = nb >> 1, dc = nb & 1;
+        const int co = chunk * 32 + s * 16 + 8 * (lane >> 5) + e;
+        float v = 0.f;
+        if (dr <= ph && dc <= pw && co < cout) v = w[((size_t)co * cin + c) * 9 + (ph + 1 - 2 * dr) * 3 + (pw + 1 - 2 * dc)];
+        wf[i] = HTraits<T>::from_f32(v);
+    }
+}
+
 size_t h16_dgrad_s2_elems(int cout, int cin) {
     size_t n = 0;
     for (int cls = 0; cls < 4; ++cls) n += cls_frag_elems(cin, cout, cls);
-    return n;
+    return n + s2g_frag_elems(cout, cin);                   // the fused layout follows the four class streams
 }
 
 int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtype, hipStream_t s) {
@@ -2136,7 +2245,16 @@ int h16_pack_dgrad_s2(const float* w_oihw, void* wf, int cout, int cin, int dtyp
         hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<__bf16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ends);
     else
         hipLaunchKernelGGL(pack_dgrad_s2_cls_h16<_Float16>, dim3(grid), dim3(256), 0, s, w_oihw, (unsigned short*)wf, cout, cin, ends);
-    return check_launch("pack_dgrad_s2_cls_h16");
+    if (int rc = check_launch("pack_dgrad_s2_cls_h16")) return rc;
+    const long long tg = (long long)s2g_frag_elems(cout, cin);
+    if (tg) {
+        unsigned short* wg = (unsigned short*)wf + acc;
+        const int g2 = (int)((tg + 255) / 256 < 8192 ? (tg + 255) / 256 : 8192);
+        if (dtype == YOLO_BF16) hipLaunchKernelGGL(pack_dgrad_s2g_h16<__bf16>, dim3(g2), dim3(256), 0, s, w_oihw, wg, cout, cin, tg);
+        else hipLaunchKernelGGL(pack_dgrad_s2g_h16<_Float16>, dim3(g2), dim3(256), 0, s, w_oihw, wg, cout, cin, tg);
+        return check_launch("pack_dgrad_s2g_h16");
+    }
+    return YOLO_OK;
 }
 
 static void fill_magics(ConvHArgs& a) {
@@ -2311,6 +2429,22 @@ int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, c
     a.Hin = ho; a.Win = wo; a.Ho = ho; a.Wo = wo;
     const long long M = (long long)n * ho * wo;
     if (M * 4 > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "dgrad_s2: too many pixels");
+    if (s2g_ok(cout, cin) && g_h_dma && (dx_ld & 7) == 0 && (dx_off & 7) == 0 && (!residual || ((r_ld & 7) == 0 && (r_off & 7) == 0))) {
+        size_t skip = 0;
+        for (int cls = 0; cls < 4; ++cls) skip += cls_frag_elems(cin, cout, cls);
+        a.wf = (const unsigned short*)wf + skip;
+        a.scale = a.shift = reinterpret_cast<const float*>(a.wf);    // the kernel's prologue fetches a table it does not use here
+        a.Cout = 4 * cin;
+        a.H = cin; a.W = (int)M; a.rows_total = 1; a.TH = 1; a.TW = wo; a.PC = ho * wo;   // H: channels per class; TW / PC: divisors
+        a.nchunks = cout / 32;
+        a.KT = a.nchunks * 4;
+        a.act = YOLO_ACT_NONE; a.out_mode = YOLO_OUT_NHWC; a.flags = residual ? YOLO_FLAG_RESIDUAL : 0;
+        a.nc5 = 1;
+        a.tiles_w = 1; a.first_wave = 0; a.stagger = 0; a.bufmask = 1; a.patch_cap = 128; a.mtab_off = 0;
+        a.cls_ph = a.cls_pw = 0;
+        if (dtype == YOLO_BF16) return launch_dma1<__bf16, 2>(a, s);
+        return launch_dma1<_Float16, 2>(a, s);
+    }
     int prmax = 1;
     a.H = ho; a.W = wo; a.rows_total = n * ho;
     pick_tile_h(ho, ho, wo, 3, 1, &a.TH, &a.TW, &prmax);
