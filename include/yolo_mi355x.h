@@ -151,6 +151,22 @@ int yolo_conv_fwd_stats(const yolo_conv_desc* d, const void* x, const void* w_pa
 int yolo_bn_stats_from_partials(const float* partial, int rows, int ld, int m, int c, const float* gamma, const float* beta,
                                 float momentum, float eps, float* running_mean, float* running_var, float* mean, float* invstd,
                                 float* scale, float* shift, void* stream);
+/* The BACKWARD reduction pass fused the same way. The gradient dy of a block's output is written last by the input-gradient
+ * convolution of the first layer that consumes it (a stride-1 convolution with the flipped weights, identity epilogue,
+ * optionally accumulating onto the running gradient); yolo_conv_dgrad_bstats is that launch (d = the descriptor yolo_conv_fwd
+ * would get, act NONE, YOLO_OUT_NHWC, [YOLO_FLAG_RESIDUAL]) and ALSO writes per-wave partial sums of du and du * (z - mean),
+ * du = dy * act'((z - mean) * scale + shift), over the ROUNDED dy it stores, for the block that produced the gradient's
+ * tensor (its raw conv output z, its batch mean / scale / shift, act = LeakyReLU or Mish). stats[row][2][ld] fp32 as above,
+ * followed by 3 * c floats of scratch. yolo_bn_act_bwd_rows = yolo_bn_act_bwd without its reduction pass, from those rows:
+ * same dgamma / dbeta / dz. yolo_conv_bstats_rows: rows (and *ld) for a descriptor, 0 = no fused kernel for it. */
+int yolo_conv_bstats_rows(const yolo_conv_desc* d, int* ld);
+int yolo_conv_dgrad_bstats(const yolo_conv_desc* d, const void* dz, const void* w_packed, const void* residual, void* dx, const void* z,
+                           int z_ld, int z_off, const float* mean, const float* scale, const float* shift, int act, float* stats,
+                           size_t stats_bytes, void* stream);
+int yolo_bn_act_bwd_rows(const void* dy, int dy_ld, int dy_off, const void* z, int z_ld, int z_off, const float* gamma,
+                         const float* mean, const float* invstd, const float* scale, const float* shift, int m, int c, int act,
+                         float* dgamma, float* dbeta, void* dz, int dz_ld, int dz_off, int dtype, float* rows, int nrows, int rows_ld,
+                         void* stream);
 /* y = act((z - mean)*scale + shift) [+ residual] (mean may be NULL = 0); out_mode YOLO_OUT_NHWC or
  * YOLO_OUT_UPSAMPLE2X. */
 int yolo_bn_act_fwd(const void* z, int z_ld, int z_off, const float* mean, const float* scale, const float* shift, const void* residual,
@@ -197,8 +213,8 @@ int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, 
 enum { YOLO_FN_FILL_ZERO = 1, YOLO_FN_COPY_D2D, YOLO_FN_NCHW_TO_NHWC, YOLO_FN_STEM_FWD, YOLO_FN_CONV_FWD, YOLO_FN_BN_STATS,
        YOLO_FN_BN_ACT_FWD, YOLO_FN_BN_ACT_BWD, YOLO_FN_UPSAMPLE2X_BWD, YOLO_FN_CONV_WGRAD, YOLO_FN_PACK_WEIGHTS_DGRAD,
        YOLO_FN_PACK_WEIGHTS_BATCH, YOLO_FN_CONV_DGRAD_S2, YOLO_FN_HEAD_GRAD_TO_NHWC, YOLO_FN_CONV_FWD_STATS,
-       YOLO_FN_BN_STATS_FROM_PARTIALS };
-#define YOLO_CALL_MAX_ARGS 22
+       YOLO_FN_BN_STATS_FROM_PARTIALS, YOLO_FN_CONV_DGRAD_BSTATS, YOLO_FN_BN_ACT_BWD_ROWS };
+#define YOLO_CALL_MAX_ARGS 24
 typedef struct yolo_call { int32_t fn; int32_t reserved; uint64_t a[YOLO_CALL_MAX_ARGS]; } yolo_call;
 typedef struct yolo_reloc { int32_t call, arg, slot, reserved; int64_t offset; } yolo_reloc;
 int yolo_run_calls(const yolo_call* calls, int n_calls, const yolo_reloc* relocs, int n_relocs, const uint64_t* slots, int n_slots,

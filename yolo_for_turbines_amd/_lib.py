@@ -33,7 +33,7 @@ class ConvOp(C.Structure):
     _fields_ = [("d", ConvDesc)] + [(n, C.c_uint64) for n in ("x", "w_packed", "scale", "shift", "residual", "y")]
 
 
-CALL_MAX_ARGS = 22
+CALL_MAX_ARGS = 24
 
 
 class Call(C.Structure):
@@ -50,7 +50,8 @@ class Reloc(C.Structure):
 FN_IDS = {name: i + 1 for i, name in enumerate((
     "yolo_fill_zero", "yolo_copy_d2d", "yolo_nchw_to_nhwc", "yolo_stem_fwd", "yolo_conv_fwd", "yolo_bn_stats", "yolo_bn_act_fwd",
     "yolo_bn_act_bwd", "yolo_upsample2x_bwd", "yolo_conv_wgrad", "yolo_pack_weights_dgrad", "yolo_pack_weights_batch",
-    "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc", "yolo_conv_fwd_stats", "yolo_bn_stats_from_partials"))}
+    "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc", "yolo_conv_fwd_stats", "yolo_bn_stats_from_partials",
+    "yolo_conv_dgrad_bstats", "yolo_bn_act_bwd_rows"))}
 
 
 class YoloLibError(RuntimeError):
@@ -101,6 +102,12 @@ _SIGS = {
     "yolo_bn_act_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_conv_bstats_rows": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+    "yolo_conv_dgrad_bstats": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_bn_act_bwd_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "yolo_upsample2x_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),
     "yolo_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 8),

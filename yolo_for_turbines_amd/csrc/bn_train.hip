@@ -427,6 +427,43 @@ __global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, in
     coef[2 * c + ch] = (float)(q / m);                  // mean(du * zhat)
 }
 
+// The same from the per-wave sums an input-gradient convolution's epilogue wrote (conv_h16.hip: d_epilogue_bstats):
+// partial[row][2][ld] fp32 = sum(du), sum(du * (z - mean)); fp64 across rows in the fixed order of bn_stats_finalize_rows.
+__global__ void bn_bwd_finalize_rows(const float* __restrict__ partial, int nrows, int ld, int m, int c, const float* __restrict__ gamma,
+                                     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     float* __restrict__ coef) {
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int lc = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
+    const int ch = blockIdx.x * FIN_CH + lc;
+    double s = 0, q = 0;
+    if (ch < c) {
+        const float* src = partial + ch;
+        const size_t step = (size_t)2 * ld;
+        int r = lane;
+        for (; r + 3 * FIN_LANES < nrows; r += 4 * FIN_LANES) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = src[(size_t)(r + u * FIN_LANES) * step]; b[u] = src[(size_t)(r + u * FIN_LANES) * step + ld]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; r < nrows; r += FIN_LANES) { s += src[(size_t)r * step]; q += src[(size_t)r * step + ld]; }
+    }
+    red[lane][lc][0] = s;
+    red[lane][lc][1] = q;
+    __syncthreads();
+    if (lane != 0 || ch >= c) return;
+    s = 0; q = 0;
+#pragma unroll 4
+    for (int l = 0; l < FIN_LANES; ++l) { s += red[l][lc][0]; q += red[l][lc][1]; }
+    q *= (double)invstd[ch];                            // sum(du * zhat)
+    dbeta[ch] = (float)s;
+    dgamma[ch] = (float)q;
+    coef[ch] = gamma[ch] * invstd[ch];
+    coef[c + ch] = (float)(s / m);
+    coef[2 * c + ch] = (float)(q / m);
+}
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const typename Elt<T>::S* __restrict__ dy, int dy_ld, int dy_off,
                                                     const typename Elt<T>::S* __restrict__ z, int z_ld, int z_off,
@@ -591,11 +628,38 @@ int yolo_conv_stats_rows(const yolo_conv_desc* d, int* ld) {
     if (ld) *ld = 0;
     if (!d || d->dtype == YOLO_F32) return 0;
     int rl[2] = {0, 0};
-    if (conv_h16_launch_stats(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rl, nullptr, nullptr) != YOLO_OK) {
+    if (conv_h16_launch_stats(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rl, nullptr, nullptr, nullptr) != YOLO_OK) {
         return 0;
     }
     if (ld) *ld = rl[1];
     return rl[0];
+}
+
+/* the same question for an input-gradient launch (a stride-1 convolution with the flipped weights, identity epilogue, optional
+ * accumulate): rows of BatchNorm-BACKWARD partial sums yolo_conv_dgrad_bstats would write (0: not available) */
+int yolo_conv_bstats_rows(const yolo_conv_desc* d, int* ld) {
+    if (ld) *ld = 0;
+    if (!d || d->dtype == YOLO_F32) return 0;
+    int rl[2] = {0, 0};
+    const ConvBStats dry = {nullptr, 0, 0, nullptr, nullptr, nullptr, 0};
+    if (conv_h16_launch_stats(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rl, nullptr, nullptr, &dry) != YOLO_OK) {
+        return 0;
+    }
+    if (ld) *ld = rl[1];
+    return rl[0];
+}
+
+int yolo_conv_dgrad_bstats(const yolo_conv_desc* d, const void* dz, const void* w_packed, const void* residual, void* dx, const void* z,
+                           int z_ld, int z_off, const float* mean, const float* scale, const float* shift, int act, float* stats,
+                           size_t stats_bytes, void* stream) {
+    if (!d || !dz || !w_packed || !dx || !z || !mean || !scale || !shift || !stats) return fail(YOLO_ERR_ARG, "conv_dgrad_bstats: null pointer");
+    if (d->dtype == YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "conv_dgrad_bstats: 16-bit convolutions only");
+    if (((d->flags & YOLO_FLAG_RESIDUAL) != 0) != (residual != nullptr)) return fail(YOLO_ERR_ARG, "conv_dgrad_bstats: residual pointer and flag disagree");
+    const ConvBStats bs = {z, z_ld, z_off, mean, scale, shift, act};
+    int rl[2];
+    const int rc = conv_h16_launch_stats(d, dz, w_packed, nullptr, nullptr, residual, dx, nullptr, stats, rl, &stats_bytes, (hipStream_t)stream, &bs);
+    if (rc == YOLO_OK && rl[0] == 0) return fail(YOLO_ERR_UNSUPPORTED, "conv_dgrad_bstats: no fused-statistics kernel for this convolution");
+    return rc;
 }
 
 int yolo_conv_fwd_stats(const yolo_conv_desc* d, const void* x, const void* w_packed, void* z, float* stats, size_t stats_bytes,
@@ -603,7 +667,7 @@ int yolo_conv_fwd_stats(const yolo_conv_desc* d, const void* x, const void* w_pa
     if (!d || !x || !w_packed || !z || !stats) return fail(YOLO_ERR_ARG, "conv_fwd_stats: null pointer");
     if (d->dtype == YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "conv_fwd_stats: 16-bit convolutions only");
     int rl[2];
-    return conv_h16_launch_stats(d, x, w_packed, nullptr, nullptr, nullptr, z, nullptr, stats, rl, &stats_bytes, (hipStream_t)stream);
+    return conv_h16_launch_stats(d, x, w_packed, nullptr, nullptr, nullptr, z, nullptr, stats, rl, &stats_bytes, (hipStream_t)stream, nullptr);
 }
 
 int yolo_bn_stats_from_partials(const float* partial, int rows, int ld, int m, int c, const float* gamma, const float* beta,
@@ -666,6 +730,29 @@ int yolo_bn_act_bwd(const void* dy, int dy_ld, int dy_off, const void* z, int z_
     int appb;
     const int anblk = ap_blocks(m, c, vn, &appb);
     YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd",
+        YOLO_SWITCH_ACT(act,
+            hipLaunchKernelGGL((bn_bwd_apply<T, ACT>), dim3(anblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
+                               (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, m, c, appb)));
+    return check_launch("bn_bwd_apply");
+}
+
+/* yolo_bn_act_bwd with the reduction pass already done by the convolution that wrote dy (yolo_conv_dgrad_bstats): `rows` are
+ * its partial sums [nrows][2][rows_ld], followed in the same buffer by room for the 3 c per-channel coefficients */
+int yolo_bn_act_bwd_rows(const void* dy, int dy_ld, int dy_off, const void* z, int z_ld, int z_off, const float* gamma,
+                         const float* mean, const float* invstd, const float* scale, const float* shift, int m, int c, int act,
+                         float* dgamma, float* dbeta, void* dz, int dz_ld, int dz_off, int dtype, float* rows, int nrows, int rows_ld,
+                         void* stream) {
+    if (!dy || !z || !gamma || !mean || !invstd || !scale || !shift || !dgamma || !dbeta || !dz || !rows) return fail(YOLO_ERR_ARG, "bn_act_bwd_rows: null pointer");
+    if (dtype == YOLO_F32) return fail(YOLO_ERR_UNSUPPORTED, "bn_act_bwd_rows: 16-bit only");
+    if (m <= 0 || c <= 0 || (c % 8) || (dy_ld % 8) || (dy_off % 8) || (z_ld % 8) || (z_off % 8) || (dz_ld % 8) || (dz_off % 8) || nrows <= 0 || rows_ld < c)
+        return fail(YOLO_ERR_ARG, "bn_act_bwd_rows: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* coef = rows + (size_t)nrows * 2 * rows_ld;
+    hipLaunchKernelGGL(bn_bwd_finalize_rows, dim3(ceil_div(c, FIN_CH)), dim3(256), 0, s, rows, nrows, rows_ld, m, c, gamma, invstd, dgamma, dbeta, coef);
+    if (int rc = check_launch("bn_bwd_finalize_rows")) return rc;
+    int appb;
+    const int anblk = ap_blocks(m, c, 8, &appb);
+    YOLO_DISPATCH_DTYPE(dtype, "bn_act_bwd_rows",
         YOLO_SWITCH_ACT(act,
             hipLaunchKernelGGL((bn_bwd_apply<T, ACT>), dim3(anblk), dim3(256), 0, s, (const Elt<T>::S*)dy, dy_ld, dy_off,
                                (const Elt<T>::S*)z, z_ld, z_off, mean, invstd, scale, shift, coef, (Elt<T>::S*)dz, dz_ld, dz_off, m, c, appb)));

@@ -98,6 +98,15 @@ int run_one(int fn, const uint64_t* a, void* s) {
         return yolo_bn_stats_from_partials(p_of<const float>(a[0]), (int)a[1], (int)a[2], (int)a[3], (int)a[4], p_of<const float>(a[5]),
                                            p_of<const float>(a[6]), f_of(a[7]), f_of(a[8]), p_of<float>(a[9]), p_of<float>(a[10]),
                                            p_of<float>(a[11]), p_of<float>(a[12]), p_of<float>(a[13]), p_of<float>(a[14]), s);
+    case YOLO_FN_CONV_DGRAD_BSTATS:
+        return yolo_conv_dgrad_bstats(p_of<const yolo_conv_desc>(a[0]), p_of<const void>(a[1]), p_of<const void>(a[2]), p_of<const void>(a[3]),
+                                      p_of<void>(a[4]), p_of<const void>(a[5]), (int)a[6], (int)a[7], p_of<const float>(a[8]),
+                                      p_of<const float>(a[9]), p_of<const float>(a[10]), (int)a[11], p_of<float>(a[12]), (size_t)a[13], s);
+    case YOLO_FN_BN_ACT_BWD_ROWS:
+        return yolo_bn_act_bwd_rows(p_of<const void>(a[0]), (int)a[1], (int)a[2], p_of<const void>(a[3]), (int)a[4], (int)a[5],
+                                    p_of<const float>(a[6]), p_of<const float>(a[7]), p_of<const float>(a[8]), p_of<const float>(a[9]),
+                                    p_of<const float>(a[10]), (int)a[11], (int)a[12], (int)a[13], p_of<float>(a[14]), p_of<float>(a[15]),
+                                    p_of<void>(a[16]), (int)a[17], (int)a[18], (int)a[19], p_of<float>(a[20]), (int)a[21], (int)a[22], s);
     default:
         return fail(YOLO_ERR_ARG, "run_calls: unknown function id %d", fn);
     }

@@ -208,9 +208,11 @@ int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, c
                         int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, hipStream_t s);
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s);
+// backward statistics of an input-gradient launch: the block that produced the convolution's input (see ConvHArgs::bz)
+struct ConvBStats { const void* z; int z_ld, z_off; const float* mean; const float* scale; const float* shift; int act; };
 int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                           const void* residual, void* y, int32_t* nan_flag, float* stats, int* rows_ld, const size_t* stats_bytes,
-                          hipStream_t s);
+                          hipStream_t s, const ConvBStats* bs);
 // the first block (3 -> 32 channels, 3x3) with a 16-bit output on the matrix cores; same arguments as yolo_stem_fwd
 int stem_h16_launch(const float* x, const float* wt, const float* scale, const float* shift, void* y, int n, int h, int w, int y_ld,
                     int y_off, int act, int dtype, int* nan_flag, hipStream_t s);

@@ -232,11 +232,13 @@ bool conv1_rs_eligible(const yolo_conv_desc* d, const void* residual) {
     if (d->cin != 256 && d->cin != 384 && d->cin != 512) return false;          // K = 768 / 1024: a 32-pixel tile does not fit a ring
     if (d->cout % 128) return false;
     // persistent workgroups of 32-pixel tiles: below ~4 tiles per workgroup the start-up (K / 2 weight registers per lane, the
-    // first ring fill) and the last, partly filled round cost more than the register-staged kernel's tiles (measured: 13x13
-    // 512->256 28.8 -> 40.3 us, 26x26 256->128 25.9 -> 35.6 us)
-    // ... and with K = 512 (16k-cycle tiles, 2-slot ring) it measured 71 vs 67 us at 26x26: the heuristic keeps K <= 384
-    const long long units = (((long long)d->n * d->h * d->w + 31) / 32) * (d->cout / 128);
-    if (d->tile != 12 && (units < 4 * 256 || d->cin > 384)) return false;
+    // first ring fill) and the last, partly filled round cost more than the register-staged kernel's tiles (measured at
+    // B = 32: 13x13 512->256 28.8 -> 40.3 us, 26x26 256->128 25.9 -> 35.6 us), and with K = 512 (16k-cycle tiles, 2-slot ring)
+    // it measured 71 vs 67 us at 26x26: the heuristic keeps K <= 384 and feature maps of >= 2048 pixels.
+    // The rule must NOT look at the batch size: this kernel adds the K products in another order than conv_patch_f32 (a lane
+    // holds 4 consecutive k of its row), and an image's result may not depend on how many neighbours share its batch
+    // (tests/test_gpu_fullsize.py: image 17 of 32 == the same image alone, bit for bit).
+    if (d->tile != 12 && ((long long)d->h * d->w < 2048 || d->cin > 384)) return false;
     if ((d->x_ld & 3) || (d->x_off & 3) || (d->y_ld & 3) || (d->y_off & 3)) return false;
     if (residual && ((d->r_ld & 3) || (d->r_off & 3))) return false;
     return true;

@@ -51,8 +51,15 @@ struct ConvHArgs {
     int prio;                            // conv3_dma_h16: prologue / epilogue at s_setprio 2 (A/B switch YOLO_DMA_PRIO=0)
     unsigned qperm;                      // conv3_dma_h16: nibble q = pixel quad of lane quad q within a 32-pixel m-tile
     int cls_ph, cls_pw;                  // MASK kernels (stride-2 input gradient): output pixel (2r+ph, 2c+pw)
-    float* stats;                        // DMA kernels, training: per-wave BatchNorm partial sums [row][2][stats_ld] (null: ordinary epilogue)
-    int stats_ld;
+    float* stats = nullptr;              // DMA kernels, training: per-wave BatchNorm partial sums [row][2][stats_ld] (null: ordinary epilogue)
+    int stats_ld = 0;
+    // backward statistics (input-gradient launches): the block that PRODUCED this convolution's input - its conv output z and
+    // BatchNorm tables. Non-null: the epilogue (identity [+ residual]) also sums du = dx * act'(bn(z)) and du * (z - mean) per channel
+    const unsigned short* bz = nullptr;
+    const float* bmean = nullptr;
+    const float* bscale = nullptr;
+    const float* bshift = nullptr;
+    int bz_ld = 0, bz_off = 0, bact = 0;
     // magic multipliers of the prologue's index divisions (a wave64 integer division is ~40 VALU instructions;
     // ~20 of them per thread were most of a 10k-cycle prologue in front of 9k cycles of matrix work)
     unsigned mg_H, mg_TW, mg_PC, mg_tn, mg_tw, mg_Hp;
@@ -1010,51 +1017,9 @@ __device__ __forceinline__ bool d_epilogue(const ConvHArgs& p, const f32x16 (&ac
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-template <typename T, int BN>
-__device__ __forceinline__ void d_epilogue_stats(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const int (&mpix)[2],
-                                                 const size_t (&ooff)[2], int ch0, int lane, int row) {
+template <int BN>
+__device__ __forceinline__ void stats_reduce_store(const ConvHArgs& p, const float (&sq)[2][BN / 64][2][8], int ch0, int lane, int row) {
     constexpr int TN = BN / 64;
-    static_assert(TN == 2, "two n-tiles per wave");
-    float sq[2][TN][2][8];                                  // [quantity][j][kp][e]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sq[a][j][kp][e] = 0.f;
-    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float live = mpix[i] < 0 ? 0.f : 1.f;        // tile padding: the lane computed a duplicate of pixel 0, counts for nothing
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                float w[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * kp + e]), __float_as_uint(acc[i][j][8 * kp + 4 + e]), false, false);
-                    w[e] = __uint_as_float(sw[0]);
-                    w[4 + e] = __uint_as_float(sw[1]);
-                }
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
-                    const float r0 = HTraits<T>::to_f32((unsigned short)(o[e] & 0xffffu)) * live;
-                    const float r1 = HTraits<T>::to_f32((unsigned short)(o[e] >> 16)) * live;
-                    sq[0][j][kp][2 * e] += r0;
-                    sq[0][j][kp][2 * e + 1] += r1;
-                    sq[1][j][kp][2 * e] = __builtin_fmaf(r0, r0, sq[1][j][kp][2 * e]);
-                    sq[1][j][kp][2 * e + 1] = __builtin_fmaf(r1, r1, sq[1][j][kp][2 * e + 1]);
-                }
-                if (mpix[i] >= 0 && ch0 + j * 64 + kp * 16 < p.Cout) *reinterpret_cast<u32x4*>(yo + ooff[i] + j * 64 + kp * 16) = o;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
     // level 16
     float l8[TN][2][8];
 #pragma unroll
@@ -1102,6 +1067,150 @@ __device__ __forceinline__ void d_epilogue_stats(const ConvHArgs& p, const f32x1
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 out = {l0[0], l0[1]};
     *reinterpret_cast<f32x2*>(p.stats + ((size_t)row * 2 + qty) * p.stats_ld + ch) = out;      // stats_ld covers the padded channel tiles
+}
+
+template <typename T, int BN>
+__device__ __forceinline__ void d_epilogue_stats(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const int (&mpix)[2],
+                                                 const size_t (&ooff)[2], int ch0, int lane, int row) {
+    constexpr int TN = BN / 64;
+    static_assert(TN == 2, "two n-tiles per wave");
+    float sq[2][TN][2][8];                                  // [quantity][j][kp][e]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sq[a][j][kp][e] = 0.f;
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float live = mpix[i] < 0 ? 0.f : 1.f;        // tile padding: the lane computed a duplicate of pixel 0, counts for nothing
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * kp + e]), __float_as_uint(acc[i][j][8 * kp + 4 + e]), false, false);
+                    w[e] = __uint_as_float(sw[0]);
+                    w[4 + e] = __uint_as_float(sw[1]);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
+                    const float r0 = HTraits<T>::to_f32((unsigned short)(o[e] & 0xffffu)) * live;
+                    const float r1 = HTraits<T>::to_f32((unsigned short)(o[e] >> 16)) * live;
+                    sq[0][j][kp][2 * e] += r0;
+                    sq[0][j][kp][2 * e + 1] += r1;
+                    sq[1][j][kp][2 * e] = __builtin_fmaf(r0, r0, sq[1][j][kp][2 * e]);
+                    sq[1][j][kp][2 * e + 1] = __builtin_fmaf(r1, r1, sq[1][j][kp][2 * e + 1]);
+                }
+                if (mpix[i] >= 0 && ch0 + j * 64 + kp * 16 < p.Cout) *reinterpret_cast<u32x4*>(yo + ooff[i] + j * 64 + kp * 16) = o;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    stats_reduce_store<BN>(p, sq, ch0, lane, row);
+}
+
+// ---- epilogue of an input-gradient launch that ALSO takes the BatchNorm-backward sums of the block that produced this
+// convolution's input (the block whose output gradient dx is): identity epilogue [+ the running gradient], rounded once, and
+// of exactly those rounded values  sum(du)  and  sum(du * (z - mean))  with  du = dx * act'((z - mean) * scale + shift)  -
+// the formula (and the fp32 operation order) of bn_bwd_partial, whose pass over dx and z this replaces. z is read here
+// once (a 16-byte row per lane, pixel and 8 channels, like the residual). Same per-wave rows as d_epilogue_stats.
+template <typename T, int BN, int ACT>
+__device__ __forceinline__ void d_epilogue_bstats(const ConvHArgs& p, const f32x16 (&acc)[2][BN / 64], const u32x4 (&rr)[2][BN / 64][2],
+                                                  bool has_res, const int (&mpix)[2], const size_t (&ooff)[2], int ch0, int lane, int row) {
+    constexpr int TN = BN / 64;
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+    size_t zoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) zoff[i] = (size_t)(mpix[i] < 0 ? 0 : mpix[i]) * p.bz_ld + p.bz_off;
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    float* srow = p.stats + ((size_t)row * 2 + ((lane >> 4) & 1)) * p.stats_ld + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const int cb = ch0 + j * 64 + kp * 16;
+            const bool chan_ok = cb < p.Cout;
+            const int cbs = chan_ok ? cb : 0;
+            f32x4 mu[2], sc[2], sh[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                mu[h] = *reinterpret_cast<const f32x4*>(p.bmean + cbs + 4 * h);
+                sc[h] = *reinterpret_cast<const f32x4*>(p.bscale + cbs + 4 * h);
+                sh[h] = *reinterpret_cast<const f32x4*>(p.bshift + cbs + 4 * h);
+            }
+            float sq[2][8];                                 // this group's 8 channels: sum(du), sum(du * (z - mean)) over the lane's two pixels
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 zv = *reinterpret_cast<const u32x4*>(p.bz + zoff[i] + cbs);
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * kp + e]), __float_as_uint(acc[i][j][8 * kp + 4 + e]), false, false);
+                    w[e] = __uint_as_float(sw[0]);
+                    w[4 + e] = __uint_as_float(sw[1]);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w[2 * e] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] & 0xffffu));
+                        w[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(rr[i][j][kp][e] >> 16));
+                    }
+                }
+                const float live = (mpix[i] >= 0 && chan_ok) ? 1.f : 0.f;
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * e + h;
+                        const float r = HTraits<T>::to_f32((unsigned short)(h ? o[e] >> 16 : o[e] & 0xffffu));
+                        const float zc = HTraits<T>::to_f32((unsigned short)(h ? zv[e] >> 16 : zv[e] & 0xffffu)) - mu[c >> 2][c & 3];
+                        const float du = r * act_grad_c<ACT>(zc * sc[c >> 2][c & 3] + sh[c >> 2][c & 3]) * live;
+                        sq[0][c] = i == 0 ? du : sq[0][c] + du;
+                        sq[1][c] = i == 0 ? du * zc : __builtin_fmaf(du, zc, sq[1][c]);
+                    }
+                }
+                if (mpix[i] >= 0 && chan_ok) *reinterpret_cast<u32x4*>(yo + ooff[i] + j * 64 + kp * 16) = o;
+            }
+            // the 32 pixels of this half, per group (16 live values instead of 64 for all four groups at once - the kernel must
+            // stay under 256 VGPRs): reduce-scatter as in stats_reduce_store, pairing (quantity), (c, c+4), (c, c+2), (c, c+1)
+            float l8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq[0][e]), __float_as_uint(sq[1][e]), false, false);
+                l8[e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            float l4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t0 = l8[e] + dpp_f<0x140>(l8[e]);
+                const float t1 = l8[e + 4] + dpp_f<0x140>(l8[e + 4]);
+                l4[e] = b3 ? t1 : t0;
+            }
+            float l2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float t0 = l4[e] + dpp_f<0x141>(l4[e]);
+                const float t1 = l4[e + 2] + dpp_f<0x141>(l4[e + 2]);
+                l2[e] = b2 ? t1 : t0;
+            }
+            const float t0 = l2[0] + dpp_f<0x4E>(l2[0]);
+            const float t1 = l2[1] + dpp_f<0x4E>(l2[1]);
+            float l1 = b1 ? t1 : t0;
+            l1 += dpp_f<0xB1>(l1);
+            if (!(lane & 1)) srow[cb] = l1;                // stats_ld covers the padded channel tiles
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // ---- epilogue of the FUSED stride-2 input gradient (conv1_dma_h16<GATH = 2>): the GEMM's output channel n = class * C + c
@@ -1362,7 +1471,9 @@ __global__ __launch_bounds__(256) void conv3_dma_h16(const ConvHArgs p) {
     // in another basic block) — ~500 cycles per store group on the 23 residual layers.
     bool saw_nan = false;
     if (p.stats != nullptr) {                                         // train-mode forward: raw z + BatchNorm partial sums
-        d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+        if (p.bz == nullptr) d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+        else if (p.bact == YOLO_ACT_LEAKY) d_epilogue_bstats<T, BN, YOLO_ACT_LEAKY>(p, acc, rr, has_res, mpix, ooff, ch0, lane, sp * 2 + wm);
+        else d_epilogue_bstats<T, BN, YOLO_ACT_MISH>(p, acc, rr, has_res, mpix, ooff, ch0, lane, sp * 2 + wm);
     } else {
     YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
                                              : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
@@ -1677,7 +1788,9 @@ __global__ __launch_bounds__(256) void conv1_dma_h16(const ConvHArgs p) {
         d_epilogue_s2g<T, BN>(p, acc, mpix, ch0);
     } else {
     if (p.stats != nullptr) {                                         // train-mode forward: raw z + BatchNorm partial sums
-        d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+        if (p.bz == nullptr) d_epilogue_stats<T, BN>(p, acc, mpix, ooff, ch0, lane, sp * 2 + wm);
+        else if (p.bact == YOLO_ACT_LEAKY) d_epilogue_bstats<T, BN, YOLO_ACT_LEAKY>(p, acc, rr, has_res, mpix, ooff, ch0, lane, sp * 2 + wm);
+        else d_epilogue_bstats<T, BN, YOLO_ACT_MISH>(p, acc, rr, has_res, mpix, ooff, ch0, lane, sp * 2 + wm);
     } else {
     YOLO_SWITCH_ACT(p.act, saw_nan = has_res ? (d_epilogue<T, BN, ACT, true>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh))
                                              : (d_epilogue<T, BN, ACT, false>(p, acc, rr, sstab, mpix, ooff, ch0, wn, fh)));
@@ -2470,7 +2583,7 @@ static int dispatch_h(ConvHArgs& a, int ks, int stride, int bn, hipStream_t s) {
 
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s) {
-    return conv_h16_launch_stats(d, x, wf, scale, shift, residual, y, nan_flag, nullptr, nullptr, nullptr, s);
+    return conv_h16_launch_stats(d, x, wf, scale, shift, residual, y, nan_flag, nullptr, nullptr, nullptr, s, nullptr);
 }
 
 // stats != nullptr: the launch must be one of the DMA kernels (conv3_dma_h16 / conv1_dma_h16) with an identity epilogue; it
@@ -2478,7 +2591,7 @@ int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, cons
 // number of partial rows and their channel stride, or 0 rows when this convolution has no fused-statistics kernel.
 int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                           const void* residual, void* y, int32_t* nan_flag, float* stats, int* rows_ld, const size_t* stats_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, const ConvBStats* bs) {
     const bool dry = rows_ld != nullptr && x == nullptr;
     if (rows_ld) { rows_ld[0] = 0; rows_ld[1] = 0; }
     if (d->cin % 32) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): cin %d must be a multiple of 32", d->cin);
@@ -2492,8 +2605,19 @@ int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf
     // the DMA kernels request their scale / shift table in the prologue whatever the epilogue does with it: in statistics mode
     // (identity epilogue, table unused) hand them readable memory - the statistics buffer itself (>= cout floats)
     if (stats != nullptr) { a.scale = stats; a.shift = stats; }
-    if (want_stats && (d->act != YOLO_ACT_NONE || d->out_mode != YOLO_OUT_NHWC || (d->flags & YOLO_FLAG_RESIDUAL)))
+    if (want_stats && (d->act != YOLO_ACT_NONE || d->out_mode != YOLO_OUT_NHWC || (!bs && (d->flags & YOLO_FLAG_RESIDUAL))))
         return dry ? YOLO_OK : fail(YOLO_ERR_ARG, "conv (16-bit): statistics need the identity epilogue (raw convolution output)");
+    if (bs) {                                               // backward statistics: sums over the gradient this launch writes
+        if (!want_stats) return fail(YOLO_ERR_ARG, "conv (16-bit): backward statistics without a statistics buffer");
+        if (d->stride != 1) return dry ? YOLO_OK : fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): backward statistics: stride-1 input gradients only");
+        if (!dry) {
+            if (!bs->z || !bs->mean || !bs->scale || !bs->shift) return fail(YOLO_ERR_ARG, "conv (16-bit): backward statistics: null pointer");
+            if ((bs->z_ld & 7) || (bs->z_off & 7) || d->cout % 8) return fail(YOLO_ERR_ARG, "conv (16-bit): backward statistics: z_ld / z_off / channels must be multiples of 8");
+            if (bs->act != YOLO_ACT_LEAKY && bs->act != YOLO_ACT_MISH) return fail(YOLO_ERR_ARG, "conv (16-bit): backward statistics: LeakyReLU or Mish block expected");
+            a.bz = (const unsigned short*)bs->z; a.bz_ld = bs->z_ld; a.bz_off = bs->z_off;
+            a.bmean = bs->mean; a.bscale = bs->scale; a.bshift = bs->shift; a.bact = bs->act;
+        }
+    }
     a.Cin = d->cin; a.Cout = d->cout;
     a.x_ld = d->x_ld; a.x_off = d->x_off; a.y_ld = d->y_ld; a.y_off = d->y_off; a.r_ld = d->r_ld; a.r_off = d->r_off;
     const int pad = d->ksize / 2;

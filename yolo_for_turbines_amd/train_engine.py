@@ -52,6 +52,9 @@ _TAPE = os.environ.get("YOLO_TRAIN_TAPE", "1") != "0"
 # BatchNorm batch statistics from the epilogue of the producing convolution (16-bit LDS-DMA kernels) instead of a separate pass
 # over z. YOLO_BN_FUSED_STATS=0 keeps the separate pass (A/B).
 _FUSED_STATS = os.environ.get("YOLO_BN_FUSED_STATS", "1") != "0"
+# 16-bit backward: the reduction pass of a block's BatchNorm backward (sum du, sum du * zhat: one read of dy and z) rides on the
+# input-gradient convolution that writes the last contribution to dy (yolo_conv_dgrad_bstats). YOLO_BN_FUSED_BSTATS=0: separate pass.
+_FUSED_BSTATS = os.environ.get("YOLO_BN_FUSED_BSTATS", "1") != "0"
 
 
 class TrainPlan:
@@ -295,6 +298,40 @@ class _Grads:
         return t.data_ptr(), v.ld, v.off, t.data_ptr(), v.ld, v.off
 
 
+def _bstats_map(plan: TrainPlan):
+    """op index i -> op index P for the input-gradient launches that can also take block P's BatchNorm-backward sums:
+    P is the only producer of i's input tensor (same channel view, plain NHWC store, BatchNorm block) and i is the FIRST
+    consumer of that tensor in forward order - the backward visits it last, so its dgrad writes the complete gradient."""
+    got = plan.__dict__.get("_bmap")
+    if got is not None:
+        return got
+    prog = plan.prog
+    producers, first_use = {}, {}
+    for j, op in enumerate(prog.ops):
+        if op["y"] is not None:
+            producers.setdefault(op["y"].buf, []).append(j)
+        for v, kind in ((op["x"], "x"), (op["res"], "res")):
+            if v is not None and v.buf not in first_use:
+                first_use[v.buf] = (j, kind)
+            elif v is not None and first_use[v.buf][0] == j:
+                first_use[v.buf] = (j, "both")
+    bmap = {}
+    if plan.dtype != "fp32" and _FUSED_BSTATS:
+        for i, op in enumerate(prog.ops):
+            xv = op["x"]
+            ps = producers.get(xv.buf, [])
+            if op["s"] != 1 or len(ps) != 1 or first_use.get(xv.buf) != (i, "x"):
+                continue
+            P = ps[0]
+            po = prog.ops[P]
+            yv = po["y"]
+            if (P < i and po["block"].batch_norm_act and po["out_mode"] == L.OUT_NHWC and yv.off == xv.off and yv.C == xv.C
+                    and yv.ld == xv.ld and xv.C == op["block"].conv.in_channels and _act_code(po["block"]) in (L.ACT_LEAKY, L.ACT_MISH)):
+                bmap[i] = P
+    plan._bmap = bmap
+    return bmap
+
+
 def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_input_grad=False, buckets=None, tape=None):
     """need: dict param-id -> bool; seeds: {symbolic buf: gradient tensor} for stand-alone blocks.
     tape (a CallTape being recorded): every launch goes through the recording proxy, every temporary stays alive in the
@@ -325,6 +362,8 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
         return t
 
     G = _Grads(plan, lib, retain)
+    bmap = _bstats_map(plan)
+    pending, bst_pool = {}, {}                                         # block index -> (rows buffer, rows, ld, dy view) left by a dgrad
     for b, t in (seeds or {}).items():
         G.state[b] = ("own", t)
     dz_scratch = {}
@@ -438,10 +477,19 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
             dz_ld = cout
             dgamma = new_grad(bn.weight)
             dbeta = new_grad(bn.bias)
-            L.check(lib.yolo_bn_act_bwd(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
-                                        st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
-                                        dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, code, plan.bn_ws.data_ptr(),
-                                        plan.bn_ws.numel(), stream), "yolo_bn_act_bwd")
+            pend = pending.pop(i, None)
+            if pend is not None and (pend[3], pend[4], pend[5]) == (dy_ptr, dy_ld, dy_off):
+                # the convolution that wrote dy left the reduction's partial sums behind: finalize + apply only
+                L.check(lib.yolo_bn_act_bwd_rows(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
+                                                 st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
+                                                 dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, code, pend[0].data_ptr(),
+                                                 pend[1], pend[2], stream), "yolo_bn_act_bwd_rows")
+                bst_pool.setdefault(pend[0].numel(), []).append(pend[0])
+            else:
+                L.check(lib.yolo_bn_act_bwd(dy_ptr, dy_ld, dy_off, plan.z[i].data_ptr(), cout, 0, bn.weight.data_ptr(), st[0].data_ptr(),
+                                            st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), m, cout, _act_code(blk),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), cout, 0, code, plan.bn_ws.data_ptr(),
+                                            plan.bn_ws.numel(), stream), "yolo_bn_act_bwd")
             grads[id(bn.weight)] = dgamma
             grads[id(bn.bias)] = dbeta
             done(bn.weight)
@@ -483,8 +531,27 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
                 if rptr:
                     d.r_ld, d.r_off = rld, roff
                     d.flags |= L.FLAG_RESIDUAL
-                L.check(lib.yolo_conv_fwd(d, dz.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), rptr, optr, 0, stream),
-                        "dgrad (stride 1)")
+                P = bmap.get(i)
+                rows = 0
+                if P is not None and P >= first_needed and not overlap:
+                    rl = plan.__dict__.setdefault("_brows", {}).get((i, d.flags))
+                    if rl is None:
+                        ldv = C.c_int(0)
+                        rl = plan._brows[(i, d.flags)] = (L.lib().yolo_conv_bstats_rows(d, C.byref(ldv)), ldv.value)
+                    rows, rld_ = rl
+                if rows:
+                    pst = plan.stats[P]
+                    numel = rows * 2 * rld_ + 3 * cin
+                    free = bst_pool.get(numel)
+                    bst = free.pop() if free else keep(torch.empty(numel, dtype=torch.float32, device=dev))
+                    L.check(lib.yolo_conv_dgrad_bstats(d, dz.data_ptr(), wp.data_ptr(), rptr, optr, plan.z[P].data_ptr(), cin, 0,
+                                                       pst[0].data_ptr(), pst[2].data_ptr(), pst[3].data_ptr(),
+                                                       _act_code(prog.ops[P]["block"]), bst.data_ptr(), numel * 4, stream),
+                            "yolo_conv_dgrad_bstats")
+                    pending[P] = (bst, rows, rld_, optr, old, ooff)
+                else:
+                    L.check(lib.yolo_conv_fwd(d, dz.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), rptr, optr, 0, stream),
+                            "dgrad (stride 1)")
             else:
                 L.check(lib.yolo_conv_dgrad_s2(dz.data_ptr(), dz_ld, 0, wp.data_ptr(), rptr, rld, roff, optr, old, ooff, B, Ho, Wo,
                                                cin, cout, code, stream), "yolo_conv_dgrad_s2")
