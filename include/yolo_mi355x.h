@@ -310,6 +310,10 @@ int yolo_decode3_ex(void* const* preds3, const int64_t* strides15, const float* 
  * reference's output order (objectness descending, ties in input order). Bit-exact contract:
  * same kept set and order as the reference for any fp32 input. center != 0 <=> box_format ==
  * "center"; every other string means (x1,y1,w,h) as is (utils.py:57-67). */
+/* Ascending sort of n UNIQUE 64-bit keys, none equal to ~0 (2,048-key chunks in LDS + rank merge, the ordering kernels of yolo_nms):
+ * the stable list sorts of calc_mAP (utils.py:206,232) as one sort of (major | minor | original index) keys. n <= 262,144. */
+size_t yolo_sort_u64_workspace_bytes(int n);
+int yolo_sort_u64(const uint64_t* keys, uint64_t* sorted, int n, void* workspace, size_t workspace_bytes, void* stream);
 size_t yolo_nms_workspace_bytes(int b, int n);
 int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_threshold, int center,
              int32_t* keep_idx, int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream);

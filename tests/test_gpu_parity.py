@@ -364,12 +364,12 @@ def test_nms_candidate_bounds_pairs_at_the_threshold(yt, thr, scale):
     assert 32 < 2 * n_pairs - len(want) < 2 * n_pairs - 32             # both outcomes occur (at scale 1 the + 1e-6 of the denominator rescues tiny boxes)
 
 
-@pytest.mark.parametrize("n,nc", [(2048, 80), (4096, 3), (4097, 80), (12288, 20), (22743, 80), (32768, 80), (33000, 80)])
+@pytest.mark.parametrize("n,nc", [(2048, 80), (4096, 3), (4097, 80), (12288, 20), (22743, 80), (32768, 80), (33000, 80), (65537, 80)])
 def test_nms_ordering_kernels_chunk_counts(yt, n, nc):
-    """The hand-written ordering (2,048-key chunks sorted in LDS + rank merge) for 1 .. 16 chunks per image, chunk
-    boundaries exactly at n, the largest grid of a forward (22,743 boxes at 608x608) and the first size that falls back
-    to the library sort: kept indices bit-exact against the C oracle, images with different numbers of candidates
-    (none, all, ties in the scores)."""
+    """The hand-written ordering (2,048-key chunks sorted in LDS + rank merge) for 1 .. 33 chunks per image, chunk
+    boundaries exactly at n, the largest grid of a forward (22,743 boxes at 608x608) and sizes that need several ranking
+    rounds of 15 chunks (> 32,768 boxes: the library sort until round 3): kept indices bit-exact against the C oracle, images
+    with different numbers of candidates (none, all, ties in the scores)."""
     rng = np.random.Generator(np.random.PCG64(n + nc))
     imgs = [gi.boxes_uniform(n, nc, 4000 + n), gi.boxes_clustered(n, nc, 4001 + n, jitter=0.15), gi.boxes_uniform(n, nc, 4002 + n)]
     imgs[1][:, 4] = 0.5 + 0.5 * rng.random(n).astype(F32)          # every box is a candidate
@@ -1093,6 +1093,33 @@ def test_map_vs_reference(yt, golden, case):
         got = yt.calc_mAP(pb, tb, thr, "center", nc)
         assert got.dim() == 0 and got.dtype == torch.float32
         assert abs(float(got) - float(g[key])) <= 2e-6, f"{case} @{thr}: {float(got)} vs {float(g[key])}"
+
+
+@pytest.mark.parametrize("n", [1, 5, 2048, 2049, 40000, 262144])
+def test_sort_u64_and_stable_two_level_order(yt, n):
+    """yolo_sort_u64 (chunk sort + rank merge as a stand-alone entry point) against torch.sort on unique keys, and the
+    two-level stable order calc_mAP builds on it against Python's own two stable list sorts (utils.py:206,232) with many ties,
+    negative zeros and negative scores."""
+    from yolo_for_turbines_amd import _lib as L
+    from yolo_for_turbines_amd.utils import _stable_order
+    g = torch.Generator().manual_seed(n)
+    keys = (torch.randint(0, 2 ** 62, (n,), generator=g, dtype=torch.int64) & ~0xfffff) | torch.arange(n, dtype=torch.int64)
+    kd = keys.cuda()
+    out = torch.empty_like(kd)
+    lib = L.lib()
+    ws = torch.empty(lib.yolo_sort_u64_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    L.check(lib.yolo_sort_u64(kd.data_ptr(), out.data_ptr(), n, ws.data_ptr(), ws.numel(), L.current_stream()))
+    assert torch.equal(out.cpu(), torch.sort(keys).values)
+    m = min(n, 5000)
+    major = torch.randint(0, 7, (m,), generator=g).float()
+    minor = (torch.randint(-8, 8, (m,), generator=g).float() / 4.0)
+    minor[::7] = -0.0
+    for desc in (True, False):
+        got = _stable_order(major.cuda(), minor.cuda(), desc).cpu().tolist()
+        rows = list(range(m))
+        rows.sort(key=lambda i: float(minor[i]), reverse=desc)        # list.sort is stable, also with reverse=True
+        rows.sort(key=lambda i: float(major[i]))
+        assert got == rows
 
 
 def test_map_known_answers(yt, golden):

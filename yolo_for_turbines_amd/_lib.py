@@ -140,6 +140,8 @@ _SIGS = {
     "yolo_decode3_ex": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "yolo_sort_u64_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "yolo_sort_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "yolo_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -32,6 +32,89 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------ decode
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// x / d for 0 <= x < 2^31 with m = ceil(2^32 / d) (d >= 2) or 0 (d == 1)
+struct DecodeMagic { unsigned mg, mgg, m3gg; };
+__device__ __forceinline__ int pp_fdiv(int x, unsigned m, int d) {
+    if (!m) return x;
+    const unsigned q = __umulhi((unsigned)x, m);
+    return (int)(q * (unsigned)d > (unsigned)x ? q - 1 : q);
+}
+static unsigned pp_magic(long long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
+static DecodeMagic decode_magic(int g) { return DecodeMagic{pp_magic(g), pp_magic((long long)g * g), pp_magic(3LL * g * g)}; }
+
+// one cell's box from its (5 + nc) values at src (LDS tile or global memory): called by the four lanes q of the cell together
+__device__ __forceinline__ void decode_cell(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
+                                            const float* __restrict__ anchors, int g, int nc, int is_pred, float* __restrict__ boxes,
+                                            int n_total, int box_offset, long long cell, const float* src, long long kstride, bool staged, int q,
+                                            const DecodeMagic mg) {
+    // cell -> (b, a, row, col) by multiply-high (cells < 2^31, checked on the host): as four 64-bit divisions per lane this index
+    // arithmetic was most of the kernel's issue time (~4.6 us per 64-cell tile)
+    const int c32 = (int)cell, gg = g * g;
+    const int b = pp_fdiv(c32, mg.m3gg, 3 * gg), r1 = c32 - b * 3 * gg;
+    const int a = pp_fdiv(r1, mg.mgg, gg), r2 = r1 - a * gg;
+    const int row = pp_fdiv(r2, mg.mg, g), col = r2 - row * g;
+    float* gp = pred + b * sb + a * sa + row * sy + col * sx;
+    if (!staged) src = gp;
+    float cls;
+    if (is_pred) {
+        const int per = (nc + 3) >> 2;
+        const int k0 = q * per, k1 = k0 + per < nc ? k0 + per : nc;
+        bool have = k0 < k1;
+        int best = k0;
+        float bv = have ? src[(5 + k0) * kstride] : 0.f;
+        int k = k0 + 1;
+        for (; k + 8 <= k1; k += 8) {                    // 8 scores in flight: one LDS round trip per 8 instead of per score
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(5 + k + u) * kstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] > bv || (v[u] != v[u] && bv == bv)) { bv = v[u]; best = k + u; }
+        }
+        for (; k < k1; ++k) {
+            const float v = src[(5 + k) * kstride];
+            if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }
+        }
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {      // lanes q and q + step: the later quarter wins only by the same rule
+            const float ov = __shfl_down(bv, step, 4);
+            const int ob = __shfl_down(best, step, 4);
+            const int oh = __shfl_down((int)have, step, 4);
+            if (oh && (!have || ov > bv || (ov != ov && bv == bv))) { bv = ov; best = ob; have = true; }
+        }
+        cls = (float)best;
+    } else {
+        cls = 0.f;
+    }
+    const float inv = (float)(1.0 / (double)g);          // `1 / grid_size` is a Python float, cast to fp32 by the multiply
+    float* o = boxes + ((size_t)b * n_total + box_offset + (size_t)a * g * g + (size_t)row * g + col) * 6;
+    if (is_pred) {
+        // The four box values of a cell go to its four lanes (x, y: sigmoid; w, h: exp * anchor): the kernel is bound by VALU
+        // issue (an expf is ~50 instructions for the whole wave however few lanes are active), and with lane 0 doing all five
+        // transcendentals the other 48 lanes of the wave waited through them. Same operations per value as before.
+        const float x = src[q * kstride];
+        const float e = expf(q < 2 ? -x : x);
+        const float v = q < 2 ? 1.f / (1.f + e) : e * anchors[2 * a + (q & 1)];
+        // in-place side effect (utils.py:106-110): what cells_to_boxes does to its argument. is_pred == 2 (detect paths, where
+        // the caller cannot observe the prediction tensor afterwards) leaves it alone: 16 bytes into every (5+nc)*4-byte cell
+        // are a partial-line write per cell, 1.7x the algorithmic 24 bytes per box of this kernel's writes
+        if (is_pred == 1) gp[q * sk] = v;
+        const float add = q == 0 ? (float)col : (float)row;
+        o[q] = inv * (q < 2 ? v + add : v);
+        if (q == 0) {
+            o[4] = sigmoid_f(src[4 * kstride]);
+            o[5] = cls;
+        }
+    } else if (q == 0) {
+        o[0] = inv * (src[0] + (float)col);
+        o[1] = inv * (src[kstride] + (float)row);
+        o[2] = inv * src[2 * kstride];
+        o[3] = inv * src[3 * kstride];
+        o[4] = src[4 * kstride];
+        o[5] = src[5 * kstride];
+    }
+}
+
 // 256 threads per 64 cells (b, a, row, col): FOUR lanes per cell. For this library's contiguous head layout (stride 1
 // along k) the 64 x (5 + nc) floats of the block are staged through LDS with full-line 16-byte loads by all 256 threads;
 // each of a cell's four lanes then finds the first maximum of a quarter of the class scores and the partial results are
@@ -40,7 +123,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 // waiting on its own loads and then on 80 dependent LDS reads: 2.5 TB/s.)
 __device__ __forceinline__ void decode_block(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
                                              const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
-                                             float* __restrict__ boxes, int n_total, int box_offset, long long blk) {
+                                             float* __restrict__ boxes, int n_total, int box_offset, long long blk, const DecodeMagic mg) {
     extern __shared__ __attribute__((aligned(16))) float tile[];           // [64][D] when sk == 1 && cells contiguous, else unused
     const int D = 5 + nc;
     const int q = threadIdx.x & 3, cl = threadIdx.x >> 2;
@@ -78,85 +161,31 @@ __device__ __forceinline__ void decode_block(float* __restrict__ pred, long long
         kstride = sk;
     }
     if (cell >= cells) return;                                               // the four lanes of a cell leave together
-    const int col = (int)(cell % g);
-    const int row = (int)((cell / g) % g);
-    const int a = (int)((cell / ((long long)g * g)) % 3);
-    const int b = (int)(cell / (3LL * g * g));
-    float* gp = pred + b * sb + a * sa + row * sy + col * sx;
-    if (!contiguous) src = gp;
-    float cls;
-    if (is_pred) {
-        const int per = (nc + 3) >> 2;
-        const int k0 = q * per, k1 = k0 + per < nc ? k0 + per : nc;
-        bool have = k0 < k1;
-        int best = k0;
-        float bv = have ? src[(5 + k0) * kstride] : 0.f;
-        int k = k0 + 1;
-        for (; k + 8 <= k1; k += 8) {                    // 8 scores in flight: one LDS round trip per 8 instead of per score
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(5 + k + u) * kstride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (v[u] > bv || (v[u] != v[u] && bv == bv)) { bv = v[u]; best = k + u; }
-        }
-        for (; k < k1; ++k) {
-            const float v = src[(5 + k) * kstride];
-            if (v > bv || (v != v && bv == bv)) { bv = v; best = k; }
-        }
-#pragma unroll
-        for (int step = 1; step <= 2; step <<= 1) {      // lanes q and q + step: the later quarter wins only by the same rule
-            const float ov = __shfl_down(bv, step, 4);
-            const int ob = __shfl_down(best, step, 4);
-            const int oh = __shfl_down((int)have, step, 4);
-            if (oh && (!have || ov > bv || (ov != ov && bv == bv))) { bv = ov; best = ob; have = true; }
-        }
-        cls = (float)best;
-    } else {
-        cls = 0.f;
-    }
-    if (q != 0) return;
-    const float inv = (float)(1.0 / (double)g);          // `1 / grid_size` is a Python float, cast to fp32 by the multiply
-    float p0 = src[0], p1 = src[kstride], p2 = src[2 * kstride], p3 = src[3 * kstride], p4 = src[4 * kstride];
-    if (is_pred) {
-        p0 = sigmoid_f(p0);
-        p1 = sigmoid_f(p1);
-        p2 = expf(p2) * anchors[2 * a];
-        p3 = expf(p3) * anchors[2 * a + 1];
-        p4 = sigmoid_f(p4);
-        // in-place side effect (utils.py:106-110): what cells_to_boxes does to its argument. is_pred == 2 (detect paths, where
-        // the caller cannot observe the prediction tensor afterwards) leaves it alone: 16 bytes into every (5+nc)*4-byte cell
-        // are a partial-line write per cell, 1.7x the algorithmic 24 bytes per box of this kernel's writes
-        if (is_pred == 1) { gp[0] = p0; gp[sk] = p1; gp[2 * sk] = p2; gp[3 * sk] = p3; }
-    } else {
-        cls = src[5 * kstride];
-    }
-    float* o = boxes + ((size_t)b * n_total + box_offset + (size_t)a * g * g + (size_t)row * g + col) * 6;
-    o[0] = inv * (p0 + (float)col);
-    o[1] = inv * (p1 + (float)row);
-    o[2] = inv * p2;
-    o[3] = inv * p3;
-    o[4] = p4;
-    o[5] = cls;
+    decode_cell(pred, sb, sa, sy, sx, sk, anchors, g, nc, is_pred, boxes, n_total, box_offset, cell, src, kstride, contiguous, q, mg);
 }
 
 __global__ void decode_kernel(float* __restrict__ pred, long long sb, long long sa, long long sy, long long sx, long long sk,
                               const float* __restrict__ anchors, int B, int g, int nc, int is_pred,
-                              float* __restrict__ boxes, int n_total, int box_offset) {
-    decode_block(pred, sb, sa, sy, sx, sk, anchors, B, g, nc, is_pred, boxes, n_total, box_offset, blockIdx.x);
+                              float* __restrict__ boxes, int n_total, int box_offset, const DecodeMagic mg) {
+    decode_block(pred, sb, sa, sy, sx, sk, anchors, B, g, nc, is_pred, boxes, n_total, box_offset, blockIdx.x, mg);
 }
 
 // the three scales of one forward in ONE launch (demo.py:44-51 / utils.py:300-309 order): at batch 32 the three separate
 // launches were launch-latency-bound (3 x ~25 us for 129 MB)
-struct DecodeScale { float* pred; long long sb, sa, sy, sx, sk; const float* anchors; int g, box_offset; long long first_block; };
+struct DecodeScale { float* pred; long long sb, sa, sy, sx, sk; const float* anchors; int g, box_offset; long long first_block; DecodeMagic mg; };
 struct Decode3Args { DecodeScale sc[3]; int B, nc, n_total, is_pred; float* boxes; };
 
 __global__ void decode3_kernel(const Decode3Args a) {
     const int k = (long long)blockIdx.x >= a.sc[2].first_block ? 2 : ((long long)blockIdx.x >= a.sc[1].first_block ? 1 : 0);
     const DecodeScale& d = a.sc[k];
     decode_block(d.pred, d.sb, d.sa, d.sy, d.sx, d.sk, d.anchors, a.B, d.g, a.nc, a.is_pred, a.boxes, a.n_total, d.box_offset,
-                 (long long)blockIdx.x - d.first_block);
+                 (long long)blockIdx.x - d.first_block, d.mg);
 }
+
+// (Round 3 tried this launch as a STREAM: persistent workgroups, 2-4 LDS tiles, the next tiles requested by LDS-DMA while the
+// current one is decoded, one barrier per tile. Slower at every depth: 3 workgroups/CU x 2 tiles 3.9 TB/s, 2 x 3 tiles 3.2,
+// 1 x 4 tiles 1.9, against 4.4 TB/s for this kernel's ~7 independent workgroups per CU - a tile's decode is ~3 us of dependent
+// LDS reads, compares and transcendentals per wave, so what the kernel needs is wave slots, not a deeper queue. DESIGN.md 7.4.)
 
 // --------------------------------------------------------------------------------- NMS
 struct SBox { float x1, y1, x2, y2, area, cls; float w, h; };   // 32 B, sorted order
@@ -499,7 +528,8 @@ __global__ __launch_bounds__(256) void nms_gather2_kernel(const float* __restric
 // image, how many keys are smaller (binary searches, all chunks of a step in flight together) — that sum plus its
 // position in its own chunk IS its final position, so the merge is a scatter. No atomics; deterministic.
 constexpr int SC = 2048;                 // keys per chunk
-constexpr int SC_MAXCH = 16;             // chunks per image handled here (n <= 32,768)
+constexpr int SC_MAXCH = 128;            // chunks per image handled here (n <= 262,144: every size that still takes the class-sorted path)
+constexpr int SC_GROUP = 15;             // chunks ranked at once by the merge kernels (registers); more chunks: several rounds
 constexpr int SC_ROW = 80;               // 8 keys (64 B) + 16 B pad per LDS row: a lane's 8 contiguous keys never share banks with its neighbours'
 __device__ __forceinline__ int sc_addr(int i) { return (i >> 3) * SC_ROW + (i & 7) * 8; }
 
@@ -579,32 +609,36 @@ __global__ __launch_bounds__(SC_THREADS) void nms_chunksort_kernel(const float* 
     }
 }
 
-// number of keys of a sorted chunk that are smaller than `key`, for up to SC_MAXCH chunks at once (one load per chunk and step in flight)
-template <int MAXC>       // MAXC >= nch - 1: slot k is chunk k (k < c) or k + 1 (the thread's own chunk is skipped)
+// number of keys of the OTHER sorted chunks that are smaller than `key`: MAXC chunks at once (one load per chunk and step in
+// flight), in rounds when the image has more than MAXC + 1 chunks (n > 32,768)
+template <int MAXC>       // slot k of a round is the (first + k)-th other chunk: chunk first + k, or the one after it from the thread's own chunk on
 __device__ __forceinline__ int rank_in_other_chunks(const unsigned long long* __restrict__ img, int nch, int c, unsigned long long key) {
-    int pos[MAXC];
-    const unsigned long long* base[MAXC];
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        pos[k] = 0;
-        const int ck = k + (k >= c ? 1 : 0);
-        base[k] = img + (size_t)(ck < nch ? ck : 0) * SC;       // clamped: unconditional loads
-    }
-#pragma unroll 1
-    for (int step = SC / 2; step >= 1; step >>= 1) {
-        unsigned long long v[MAXC];
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) v[k] = base[k][pos[k] + step - 1];
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) pos[k] += v[k] < key ? step : 0;
-    }
     int total = 0;
+#pragma unroll 1
+    for (int first = 0; first < nch - 1; first += MAXC) {
+        int pos[MAXC];
+        const unsigned long long* base[MAXC];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        // positions are in [0, SC - 1]: the last element needs its own test
-        const bool live = k + (k >= c ? 1 : 0) < nch;
-        const int full = pos[k] + ((live && pos[k] == SC - 1 && base[k][SC - 1] < key) ? 1 : 0);
-        total += live ? full : 0;
+        for (int k = 0; k < MAXC; ++k) {
+            pos[k] = 0;
+            const int ck = first + k + (first + k >= c ? 1 : 0);
+            base[k] = img + (size_t)(ck < nch ? ck : 0) * SC;       // clamped: unconditional loads
+        }
+#pragma unroll 1
+        for (int step = SC / 2; step >= 1; step >>= 1) {
+            unsigned long long v[MAXC];
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) v[k] = base[k][pos[k] + step - 1];
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) pos[k] += v[k] < key ? step : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            // positions are in [0, SC - 1]: the last element needs its own test
+            const bool live = first + k + (first + k >= c ? 1 : 0) < nch;
+            const int full = pos[k] + ((live && pos[k] == SC - 1 && base[k][SC - 1] < key) ? 1 : 0);
+            total += live ? full : 0;
+        }
     }
     return total;
 }
@@ -655,6 +689,33 @@ __global__ __launch_bounds__(256) void nms_merge2_kernel(const float* __restrict
     grank[(size_t)b * n + q] = (int)(unsigned)((k >> 20) & 0xfffffull);
     if ((q & 63) == 0) blk_lo[(size_t)b * W + (q >> 6)] = cls;
     if ((q & 63) == 63 || q == nv - 1) blk_hi[(size_t)b * W + (q >> 6)] = cls;
+}
+
+// ---- the same two launches as a stand-alone ascending sort of UNIQUE 64-bit keys (none equal to ~0): the orderings of
+// calc_mAP (utils.py:206,232: detections by class and descending objectness, ground truths by class and image - Python's
+// stable sorts become one sort of (major | minor | original index) keys)
+__global__ __launch_bounds__(SC_THREADS) void sort_chunks_kernel(const unsigned long long* __restrict__ in, int n, unsigned long long* __restrict__ chunked) {
+    __shared__ __attribute__((aligned(16))) char lds[(SC / 8) * SC_ROW];
+    const int c = blockIdx.x, tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < (1 << SC_LG); ++e) {
+        const int loc = e * SC_THREADS + tid, i = c * SC + loc;
+        *reinterpret_cast<unsigned long long*>(lds + sc_addr(loc)) = i < n ? in[i] : ~0ull;
+    }
+    __syncthreads();
+    chunk_sort_lds<SC_LG>(lds, tid);
+#pragma unroll
+    for (int e = 0; e < (1 << SC_LG); ++e) {
+        const int loc = e * SC_THREADS + tid;
+        chunked[(size_t)c * SC + loc] = *reinterpret_cast<const unsigned long long*>(lds + sc_addr(loc));
+    }
+}
+template <int MAXC>
+__global__ __launch_bounds__(256) void sort_merge_kernel(const unsigned long long* __restrict__ chunked, int nch, unsigned long long* __restrict__ out) {
+    const int c = blockIdx.x >> 3, ploc = (blockIdx.x & 7) * 256 + threadIdx.x;
+    const unsigned long long key = chunked[(size_t)c * SC + ploc];
+    if (key == ~0ull) return;                                   // padding of the last chunk
+    out[ploc + rank_in_other_chunks<MAXC>(chunked, nch, c, key)] = key;
 }
 
 // The words of the diagonal and of the SCAN_NEAR column blocks after it are ALSO stored as near[b][rb][d][lane] (d = cb - rb):
@@ -1365,12 +1426,13 @@ int yolo_decode(void* pred, const int64_t* s, const float* anchors, int b, int g
     if (!is_pred && nc != 1) return fail(YOLO_ERR_ARG, "decode: targets must have last dim 6");
     if (box_offset < 0 || box_offset + 3 * g * g > n_total) return fail(YOLO_ERR_ARG, "decode: box range outside n_total");
     const long long cells = (long long)b * 3 * g * g;
+    if (cells > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "decode: too many cells");
     const int D = 5 + nc;
     const size_t lds = (size_t)64 * D * sizeof(float);
     if (lds > 64 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "decode: %d classes exceed the staging tile", nc);
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (float*)pred,
                        (long long)s[0], (long long)s[1], (long long)s[2], (long long)s[3], (long long)s[4], anchors, b, g, nc,
-                       is_pred, boxes, n_total, box_offset);
+                       is_pred, boxes, n_total, box_offset, decode_magic(g));
     return check_launch("decode");
 }
 
@@ -1390,7 +1452,8 @@ int yolo_decode3_ex(void* const* preds3, const int64_t* strides15, const float* 
         const int g = grids3[k];
         if (!preds3[k] || !anchors3[k] || g <= 0) return fail(YOLO_ERR_ARG, "decode3: bad scale %d", k);
         DecodeScale& d = a.sc[k];
-        d.pred = (float*)preds3[k]; d.anchors = anchors3[k]; d.g = g; d.box_offset = off; d.first_block = blocks;
+        d.pred = (float*)preds3[k]; d.anchors = anchors3[k]; d.g = g; d.box_offset = off; d.first_block = blocks; d.mg = decode_magic(g);
+        if ((long long)b * 3 * g * g > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "decode3: too many cells");
         d.sb = strides15[5 * k]; d.sa = strides15[5 * k + 1]; d.sy = strides15[5 * k + 2]; d.sx = strides15[5 * k + 3]; d.sk = strides15[5 * k + 4];
         off += 3 * g * g;
         blocks += ((long long)b * 3 * g * g + 63) / 64;
@@ -1401,6 +1464,25 @@ int yolo_decode3_ex(void* const* preds3, const int64_t* strides15, const float* 
     if (lds > 64 * 1024) return fail(YOLO_ERR_UNSUPPORTED, "decode: %d classes exceed the staging tile", nc);
     hipLaunchKernelGGL(decode3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("decode3");
+}
+
+size_t yolo_sort_u64_workspace_bytes(int n) { return n > 0 ? (size_t)ceil_div(n, SC) * SC * sizeof(unsigned long long) : 8; }
+
+int yolo_sort_u64(const uint64_t* keys, uint64_t* sorted, int n, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n <= 0) return YOLO_OK;
+    if (!keys || !sorted || !workspace) return fail(YOLO_ERR_ARG, "sort_u64: null pointer");
+    if (n > SC * SC_MAXCH) return fail(YOLO_ERR_UNSUPPORTED, "sort_u64: n = %d exceeds %d keys", n, SC * SC_MAXCH);
+    if (workspace_bytes < yolo_sort_u64_workspace_bytes(n)) return fail(YOLO_ERR_WORKSPACE, "sort_u64: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = ceil_div(n, SC);
+    unsigned long long* chunked = (unsigned long long*)workspace;
+    hipLaunchKernelGGL(sort_chunks_kernel, dim3(nch), dim3(SC_THREADS), 0, st, (const unsigned long long*)keys, n, chunked);
+    if (int rc = check_launch("sort_chunks")) return rc;
+    const dim3 gb(nch * 8);
+    if (nch <= 3) hipLaunchKernelGGL(sort_merge_kernel<2>, gb, dim3(256), 0, st, chunked, nch, (unsigned long long*)sorted);
+    else if (nch <= 9) hipLaunchKernelGGL(sort_merge_kernel<8>, gb, dim3(256), 0, st, chunked, nch, (unsigned long long*)sorted);
+    else hipLaunchKernelGGL(sort_merge_kernel<SC_GROUP>, gb, dim3(256), 0, st, chunked, nch, (unsigned long long*)sorted);
+    return check_launch("sort_merge");
 }
 
 size_t yolo_nms_workspace_bytes(int b, int n) {
@@ -1451,7 +1533,7 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
             if (nch <= 3) hipLaunchKernelGGL(nms_merge1_kernel<2>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
             else if (nch <= 5) hipLaunchKernelGGL(nms_merge1_kernel<4>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
             else if (nch <= 9) hipLaunchKernelGGL(nms_merge1_kernel<8>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
-            else hipLaunchKernelGGL(nms_merge1_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
+            else hipLaunchKernelGGL(nms_merge1_kernel<SC_GROUP>, gb, dim3(256), 0, st, w.chunked, w.chunk_valid, nch, n, w.keys_out, w.nvalid, w.row_any, W);
             rc = check_launch("nms order 1");
             if (rc) return rc;
             hipLaunchKernelGGL(nms_chunksort_kernel<2>, ga, dim3(SC_THREADS), 0, st, boxes, w.keys_out, w.nvalid, n, obj_threshold, w.chunked,
@@ -1462,7 +1544,7 @@ int yolo_nms(const float* boxes, int b, int n, double iou_threshold, double obj_
             if (nch <= 3) hipLaunchKernelGGL(nms_merge2_kernel<2>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
             else if (nch <= 5) hipLaunchKernelGGL(nms_merge2_kernel<4>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
             else if (nch <= 9) hipLaunchKernelGGL(nms_merge2_kernel<8>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
-            else hipLaunchKernelGGL(nms_merge2_kernel<SC_MAXCH - 1>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
+            else hipLaunchKernelGGL(nms_merge2_kernel<SC_GROUP>, gb, dim3(256), 0, st, boxes, w.chunked, w.nvalid, nch, n, W, center, sorted2, w.order, w.grank, w.sbox, w.blk_lo, w.blk_hi);
             rc = check_launch("nms order 2");
             if (rc) return rc;
             w.keys_out = sorted2;

@@ -229,6 +229,29 @@ def build_targets(boxes, anchors, image_size, counts=None, ignore_iou_threshold=
     return tuple(outs)
 
 
+def _stable_order(major, minor, descending_minor):
+    """Indices that order rows by (``major`` ascending, ``minor`` ascending / descending, original position): what two stable
+    Python list sorts produce (utils.py:206,232). ``major`` holds small non-negative integers (class ids), ``minor`` any
+    floats. One sort of unique 64-bit keys  major (11 bits) | orderable(minor) (32) | index (20)  by ``yolo_sort_u64`` (the
+    NMS ordering kernels); above 262,144 rows or 2,047 classes the same two stable sorts run through ``torch.sort``."""
+    n = int(major.shape[0])
+    if n == 0:
+        return torch.empty(0, dtype=torch.long, device=major.device)
+    if n > 262144 or n >= (1 << 20) or float(major.max()) > 2046:
+        o = torch.sort(minor, descending=descending_minor, stable=True).indices
+        return o[torch.sort(major[o], stable=True).indices]
+    bits = (minor.float() + 0.0).contiguous().view(torch.int32).to(torch.int64) & 0xffffffff      # -0.0 -> +0.0: equal in Python
+    u = torch.where(bits >= 0x80000000, bits ^ 0xffffffff, bits | 0x80000000)                     # ascending-orderable
+    if descending_minor:
+        u = 0xffffffff - u
+    keys = (major.to(torch.int64) << 52) | (u << 20) | torch.arange(n, dtype=torch.int64, device=major.device)
+    out = torch.empty_like(keys)
+    with torch.cuda.device(major.device):
+        ws = torch.empty(L.lib().yolo_sort_u64_workspace_bytes(n), dtype=torch.uint8, device=major.device)
+        L.check(L.lib().yolo_sort_u64(keys.data_ptr(), out.data_ptr(), n, ws.data_ptr(), ws.numel(), L.current_stream()), "yolo_sort_u64")
+    return out & 0xfffff
+
+
 # ------------------------------------------------------------------------------ mAP
 def calc_mAP(pred_boxes, true_boxes, iou_threshold=0.5, box_format="center", num_classes=20):
     """Drop-in for the reference's ``calc_mAP`` (utils.py:193-274): rows ``[image_id, cx, cy, w, h, obj, class]``
@@ -246,13 +269,9 @@ def calc_mAP(pred_boxes, true_boxes, iou_threshold=0.5, box_format="center", num
         return t[ok]
     dets, gts = class_rows(dets), class_rows(gts)
     # detections: objectness descending, then class ascending — both stable, so ties keep list order (list.sort)
-    o = torch.sort(dets[:, 5], descending=True, stable=True).indices
-    o = o[torch.sort(dets[o, 6], stable=True).indices]
-    dets = dets[o].contiguous()
+    dets = dets[_stable_order(dets[:, 6], dets[:, 5], descending_minor=True)].contiguous()
     # ground truths: image ascending, then class ascending (stable): per (class, image) the list order survives
-    o = torch.sort(gts[:, 0], stable=True).indices
-    o = o[torch.sort(gts[o, 6], stable=True).indices]
-    gts = gts[o].contiguous()
+    gts = gts[_stable_order(gts[:, 6], gts[:, 0], descending_minor=False)].contiguous()
 
     def offsets(t):
         cnt = torch.bincount(t[:, 6].long(), minlength=nc)[:nc]
