@@ -517,6 +517,15 @@ def main():
             e = entry(t_f, name, "FusedYOLOLoss (3 HIP kernels per scale; same values/gradients as loss.py:29-81)")
             t_p = ydist.timed_steps(make_step(yt.YOLOLoss(), autocast_dtype), args.train_steps, 2, dist, device)
             e["with_pytorch_loss"] = entry(t_p, name, "YOLOLoss (the reference's boolean-mask PyTorch ops)")
+            # the same eager step with the NaN guards of model.py:175,183-184 reported a step later instead of inside the forward
+            # (nan_check = "deferred": no host sync between forward and backward; same exceptions). Default stays the reference's.
+            tm._engine.nan_check = "deferred"
+            try:
+                t_d = ydist.timed_steps(make_step(yt.FusedYOLOLoss(), autocast_dtype), args.train_steps, 2, dist, device)
+                tm._engine.flush_nan()
+            finally:
+                tm._engine.nan_check = True
+            e["deferred_nan_guard"] = entry(t_d, name, "FusedYOLOLoss; eager, NaN guards read without a host sync inside the step")
             if dist is None:                            # no process group: capture never sees a collective (a forced 1-rank
                 try:                                    # RCCL group inside a capture crashed once in ~10 runs)
                     t_g = graph_leg(autocast_dtype)

@@ -168,6 +168,40 @@ def test_nan_guards(yt):
         m(x)
 
 
+def test_nan_guard_modes_in_train_mode(yt):
+    """Train-mode forward: the guards of model.py:175,183-184 raise inside the forward by default; with
+    ``nan_check = "deferred"`` the same exception comes from the next forward (train or eval) or from ``flush_nan()``, and a
+    clean step in between raises nothing."""
+    c = gi.NET_CASES["nc2_s128_b1_leaky"]
+    m = _model(yt, c).train()
+    good = onet.synth_input(5, 2, 64).cuda()
+    bad = good.clone()
+    bad[1, 2, 7, 9] = float("nan")
+    with pytest.raises(AssertionError, match="NaN in the input"):
+        m(bad)
+    m._engine.nan_check = "deferred"
+    m(good)
+    m(good)
+    m._engine.flush_nan()                                 # nothing to report
+    preds = m(bad)                                        # returns; the guard is queued
+    assert len(preds) == 3
+    torch.cuda.synchronize()                              # (the poll of a later forward never waits: let the event complete)
+    with pytest.raises(AssertionError, match="NaN in the input"):
+        m(good)
+    m(good)                                               # the report was consumed
+    m(bad)
+    with pytest.raises(AssertionError, match="NaN in the input"):
+        m._engine.flush_nan()
+    m._engine.flush_nan()                                 # idempotent
+    for _ in range(12):                                   # more clean steps than slots without a sync in between
+        m(good)
+    m._engine.flush_nan()
+    m(bad)
+    m.eval()
+    with torch.no_grad(), pytest.raises(AssertionError, match="NaN in the input"):
+        m(good)                                           # an eval forward flushes (and waits)
+
+
 def test_outputs_are_writable_and_fresh(yt):
     c = gi.NET_CASES["nc2_s128_b1_leaky"]
     m = _model(yt, c)

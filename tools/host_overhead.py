@@ -6,7 +6,8 @@ Three numbers per configuration:
     last launch has been handed to the runtime - the host cost proper, with an empty queue in front of it;
   * steady state: N steps without synchronising - host time to enqueue them (once the host is faster than the GPU this reads
     the GPU's time: the runtime's queue pushes back) and time until the GPU has finished them;
-YOLO_TRAIN_TAPE=0 selects the per-launch path (no launch tables) for A/B."""
+YOLO_TRAIN_TAPE=0 selects the per-launch path (no launch tables) for A/B; NAN_CHECK=deferred|off sets the model's NaN guard mode
+(default: the reference's immediate guard, one host sync inside every forward); GRAPH=1 adds the whole step as one HIP graph."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +19,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 B, S, nc = 32, 416, 2
 dev = torch.device("cuda:0")
 m = yt.YOLOv3(num_classes=nc).to(dev).train()
+_mode = os.environ.get("NAN_CHECK", "immediate")
+m._engine.nan_check = {"immediate": True, "deferred": "deferred", "off": False}[_mode]
 opt = (torch.optim.SGD if os.environ.get("TORCH_SGD") else yt.SGD)(m.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
 anchors = gi.TRAIN_CASE["anchors"]
 sa = (torch.tensor(anchors) * torch.tensor([S // 32, S // 16, S // 8]).view(3, 1, 1)).to(dev)
@@ -63,9 +66,20 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 idle.sort()
-print(f"{dtype}: idle-GPU enqueue {1e3 * idle[len(idle) // 2]:.2f} ms/step (median of {steps}; "
+print(f"{dtype} nan_check={_mode}: idle-GPU enqueue {1e3 * idle[len(idle) // 2]:.2f} ms/step (median of {steps}; "
       + ", ".join(f"{k} {1e3 * v / steps:.2f}" for k, v in parts.items()) + f") | steady state: host enqueue "
       f"{1e3 * (t1 - t0) / steps:.2f} ms/step, until finished {1e3 * (t2 - t0) / steps:.2f} ms/step")
+m._engine.flush_nan()
+if os.environ.get("GRAPH"):
+    gs = yt.GraphedTrainStep(m, opt, list(sa), x, tg, autocast_dtype=ac)
+    for _ in range(3):
+        gs(x, tg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs(x, tg)
+    torch.cuda.synchronize()
+    print(f"{dtype}: whole step as one HIP graph {1e3 * (time.perf_counter() - t0) / steps:.2f} ms/step")
 if os.environ.get("HOST_PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile()

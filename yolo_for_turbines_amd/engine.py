@@ -390,7 +390,12 @@ class ModelState:
         self._gen = 0                     # bumped whenever packed state is declared out of date by hand (invalidate, mark_unfolded)
         self._fast = {}                   # (id(blocks), device, dtype) -> (gen, blocks, [(owner dict, key, tensor, version, address)])
         self._plans = {}
+        # True: the NaN guards of model.py:175,183-184 raise inside the forward that saw the NaN (one host sync per forward).
+        # "deferred" (train mode only): they raise at the start of the next forward, or from flush_nan() - the eager fine-tune
+        # step then never waits for its own forward before enqueueing the backward. False: no guard.
         self.nan_check = True
+        self._train_nan_pending = None   # not None: deferred guards are queued (see defer_nan)
+        self._nan_host, self._nan_queue, self._nan_next = None, [], 0
         self.tile_override = None
         self.compute_dtype = None        # None: follow torch.autocast (fp32 outside it); or "fp32" / "fp16" / "bf16"
         self.ddp = None                  # (torch.distributed module, bucket MB) when data-parallel (dist.data_parallel)
@@ -539,6 +544,8 @@ class ModelState:
             raise RuntimeError("yolo_for_turbines_amd runs on MI355X only: move the model and the input to the GPU "
                                "(there is no CPU fallback)")
         L.lib()                                                   # fail loudly if the HIP library is missing
+        if self._train_nan_pending is not None and not (model.training and torch.is_grad_enabled()):
+            self.flush_nan()                                      # (forward_train does it under the right device)
         if model.training and torch.is_grad_enabled():
             from . import train_engine
             return train_engine.forward_train(self, model, x)
@@ -588,11 +595,60 @@ class ModelState:
                 preds = [t.to(hd) for t in preds]
         return preds
 
+    # ---- deferred NaN guard (train mode, ``nan_check = "deferred"``)
+    # The flag of every forward is copied (by an ordinary kernel: no blit path, no host sync) into a slot of pinned host memory,
+    # followed by an event. Later forwards look at the slots whose event has completed - never waiting for the GPU - so the host
+    # keeps running ahead of the device; flush_nan() waits for all of them.
+    _NAN_SLOTS = 8
+
+    def defer_nan(self, flag_tensor):
+        if self._nan_host is None:
+            self._nan_host = torch.zeros(self._NAN_SLOTS, dtype=torch.int32).pin_memory()
+            self._nan_queue = []
+        if len(self._nan_queue) >= self._NAN_SLOTS:
+            self.poll_nan(block_oldest=True)
+        k = self._nan_next % self._NAN_SLOTS
+        self._nan_next += 1
+        L.check(L.lib().yolo_copy_d2d(self._nan_host.data_ptr() + 4 * k, flag_tensor.data_ptr(), 4, L.current_stream()), "nan flag copy")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._nan_queue.append((ev, k))
+        self._train_nan_pending = True
+
+    def poll_nan(self, block_oldest=False, block_all=False):
+        q = self._nan_queue
+        while q:
+            ev, k = q[0]
+            if block_all or block_oldest:
+                ev.synchronize()
+                block_oldest = False
+            elif not ev.query():
+                break
+            q.pop(0)
+            flag = int(self._nan_host[k])
+            if flag:
+                for e2, _ in q:                                    # one exception per poisoned run: drop the younger reports
+                    e2.synchronize()
+                q.clear()
+                self._train_nan_pending = None
+                self._raise_flag(flag)
+        if not q:
+            self._train_nan_pending = None
+
+    def flush_nan(self):
+        """Wait for and read the NaN guards that train-mode forwards left pending (``nan_check = "deferred"``); raises like the
+        forward would have."""
+        if self._train_nan_pending is not None:
+            self.poll_nan(block_all=True)
+
     def raise_on_nan(self, flag_tensor):
         # (against the 0.2 ms gap after an fp32 forward, tried and measured equal on the same box: a copy into pinned memory +
         # event wait, the same with a Python busy-poll on the event, ROC_ACTIVE_WAIT_TIMEOUT and HSA_ENABLE_INTERRUPT=0 -
         # 1,673-1,690 images/s either way, so the gap is not the host's wake-up)
-        flag = int(flag_tensor.item())
+        self._raise_flag(int(flag_tensor.item()))
+
+    @staticmethod
+    def _raise_flag(flag):
         assert not (flag & 1), "NaN in the input tensor"          # model.py:175
         if flag & 2:
             raise ValueError("Nan in layer")                      # model.py:183-184

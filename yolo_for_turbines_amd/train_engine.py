@@ -690,6 +690,8 @@ def forward_train(state, model, x):
     if Cc != model.in_channels or H != W or H % 32:
         raise ValueError(f"input must be (B,{model.in_channels},S,S) with S a multiple of 32, got {tuple(x.shape)}")
     with torch.cuda.device(x.device):
+        if state._train_nan_pending is not None:
+            state.poll_nan()                              # guards left by earlier train-mode forwards (nan_check = "deferred"): never waits
         dt = resolve_dtype(state.compute_dtype)           # autocast (train.py:53) selects the 16-bit kernels
         key = ("train", B, H, x.device.index, dt)
         plan = state._plans.get(key)
@@ -707,7 +709,13 @@ def forward_train(state, model, x):
             plist = plan._plist = [p for p in model.parameters()]
         holder = (state, model, plan, plist)
         preds = YoloTrainFn.apply(x, holder, *plist)
-        if state.nan_check:
+        if state.nan_check == "deferred":
+            # The guard's flag read is a host sync that waits for this forward's own kernels, and the loss / backward can only be
+            # enqueued after it: ~1 ms of idle queue per eager step. Deferred: the flag goes to pinned host memory behind the
+            # forward and is looked at by later forwards once its event has completed (or by flush_nan()) - same exception, a
+            # step or two later, and the host never waits for the device.
+            state.defer_nan(plan.nan_flag)
+        elif state.nan_check:
             state.raise_on_nan(plan.nan_flag)
         hd = state.head_dtype()
         if hd != torch.float32:                       # what autocast hands the reference's loss (train.py:53-65); the cast is an
