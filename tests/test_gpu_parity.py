@@ -1742,6 +1742,74 @@ def test_stride2_conv_as_gathered_gemm(yt, case, dtype):
     assert torch.equal(outs[0], outs[1])
 
 
+WS_CASES = [  # (B, H, W, cin, cout, stride, residual, act, y_ld, y_off): conv3_ws_h16 (3x3, <= 64 channels, weights in registers; tile 14)
+    (2, 16, 32, 32, 64, 1, False, 1, 64, 0),         # exactly 2 x 2 tiles per image
+    (1, 52, 52, 32, 64, 1, True, 1, 64, 0),          # ragged tiles in both directions (52 = 6.5 x 8 = 3.25 x 16), residual
+    (3, 13, 19, 32, 40, 1, True, 2, 96, 32),         # cout not a multiple of 32; odd sizes; slice of a wider buffer; Mish
+    (2, 26, 26, 64, 32, 1, True, 0, 32, 0),          # the input-gradient shape: 64 -> 32, identity epilogue + accumulate
+    (1, 40, 24, 64, 24, 1, False, 1, 24, 0),         # 64 -> 24
+    (2, 32, 64, 32, 64, 2, False, 1, 64, 0),         # stride 2: 16 x 32 outputs
+    (1, 52, 44, 32, 48, 2, False, 2, 64, 16),        # stride 2, ragged, channel padding, view
+    (1, 208, 208, 32, 64, 1, True, 1, 64, 0),        # more tiles (338) than one round of some workgroups: the persistent loop and both buffers
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WS_CASES)
+def test_small_channel_3x3_weights_in_registers(yt, case, dtype):
+    """conv3_ws_h16 through the C-ABI (tile 14, and the default tile, which must pick it): image borders (zero page), ragged tiles,
+    persistent workgroups alternating two patch buffers, residual / accumulate, ld / off views, channel padding, stride 2.
+    Reference: fp64 convolution of the same rounded operands; round 2's kernel (tile 5) within the same tolerance."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, W, cin, cout, stride, residual, act, y_ld, y_off = case
+    code, tdt, tol = {"bf16": (L.BF16, torch.bfloat16, 1e-2), "fp16": (L.F16, torch.float16, 2e-3)}[dtype]
+    g = torch.Generator().manual_seed(1700 + cin + cout + H + W)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn((B, H, W, cin), generator=g).to(tdt)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (cin * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    y0 = torch.randn((B, Ho, Wo, y_ld), generator=g).to(tdt)
+    r = torch.randn((B, Ho, Wo, cout), generator=g).to(tdt) if residual else None
+    xd, sd, shd, wd = x.to(dev), scale.to(dev), shift.to(dev), w.to(dev)
+    rd = r.to(dev) if residual else None
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, 3, code), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, 3, code, st))
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(tdt).double(), stride=stride, padding=1)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.1) if act == 1 else (F.mish(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + r.double()
+    outs = []
+    for tile in (14, 0, 5):
+        yd = y0.clone().to(dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        d = L.ConvDesc(n=B, h=H, w=W, cin=cin, cout=cout, ksize=3, stride=stride, x_ld=cin, x_off=0, y_ld=y_ld, y_off=y_off, r_ld=cout, r_off=0,
+                       act=act, out_mode=L.OUT_NHWC, dtype=code, flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
+        L.check(lib.yolo_conv_fwd(d, xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                  yd.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        got = yd.cpu()
+        err = float((got[..., y_off:y_off + cout].double() - ref).abs().max() / ref.abs().max())
+        assert err <= tol, (tile, err)
+        keep = torch.ones(y_ld, dtype=torch.bool)
+        keep[y_off:y_off + cout] = False
+        assert torch.equal(got[..., keep], y0[..., keep])
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])
+    xn = xd.clone()
+    xn[0, H // 2, W // 2, 3] = float("nan")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    d.tile = 14
+    L.check(lib.yolo_conv_fwd(d, xn.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                              y0.clone().to(dev).data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 2
+
+
 S2_DGRAD_CASES = [  # (B, Ho, cin, cout, residual, dz_ld, dx_ld, dx_off)
     (2, 13, 32, 64, False, 64, 32, 0),           # the stem's successor: four classes in ONE n tile; 338 dz pixels, ragged last tile
     (1, 26, 64, 128, True, 128, 64, 0),          # two n tiles, accumulate into the running gradient

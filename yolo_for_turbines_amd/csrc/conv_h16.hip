@@ -2581,6 +2581,224 @@ static int dispatch_h(ConvHArgs& a, int ks, int stride, int bn, hipStream_t s) {
     return bn == 128 ? launch_h<T, 3, 2, 128>(a, s) : launch_h<T, 3, 2, 64>(a, s);
 }
 
+// =====================================================================================================
+// conv3_ws_h16 (round 3): the 3x3 layers with <= 64 input AND output channels (32 -> 64 at 208^2, its input gradient 64 -> 32,
+// the stride-2 32 -> 64 at 416 -> 208^2), weights in REGISTERS.
+// conv_patch_h16_n64 gives such a layer one 128-pixel tile per block: 36 MFMAs of matrix work per wave behind a prologue of index
+// arithmetic, a register-staged patch and an LDS round trip - 173 us for a layer whose bytes take ~85 us (32 -> 64 with the
+// residual) and whose matrix work takes ~25. These layers are a stream: the whole filter bank is 36 KB, so
+//   * a wave keeps ALL weight fragments in registers (9 taps x Cin/16 k-steps x Cout/32 n-tiles x 4 VGPRs = 144) for the lifetime
+//     of a PERSISTENT workgroup (2 per CU) and walks 8 x 16-pixel output tiles;
+//   * the tile's input patch with halo ((8s+1... ) x (16s+...) pixels, s = stride) arrives by LDS-DMA into a double buffer while
+//     the previous tile is multiplied: one wait + ONE barrier per tile, placed between the MFMA phase and the epilogue, so the
+//     stores of tile t overlap the request and the matrix work of tile t + 1;
+//   * patch rows are Cin x 2 bytes with the 16-byte chunks XOR-swizzled on the DMA's source side (by (p >> 2) & 3 for 64-byte
+//     rows, (p >> 1) & 7 for 128-byte rows): 16 consecutive pixels cover all banks (stride 2: two-way);
+//   * operand swap as in the other DMA kernels: weights = A, pixels = B, D = [channel][pixel]; one v_permlane32_swap per register
+//     pair leaves a lane with 8 consecutive channels of its pixel: 16-byte stores / residual loads.
+// Halo pixels outside the image read the zero page.
+constexpr int WS_TH = 8, WS_TW = 16;
+struct ConvWsArgs {
+    const unsigned short* x;
+    const unsigned short* wf;
+    const float* scale;
+    const float* shift;
+    const unsigned short* res;
+    unsigned short* y;
+    int* nan_flag;
+    int N, Hin, Win, Ho, Wo;
+    int x_ld, x_off, y_ld, y_off, r_ld, r_off;
+    int Cout, KT, act, flags;
+    int tiles_w, tiles_per_img, total_tiles;
+    unsigned mg_tpi, mg_tw;
+};
+
+template <typename T, int CIN, int NT, int STRIDE, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
+    typedef typename HTraits<T>::vec vec;
+    constexpr int PR = STRIDE * (WS_TH - 1) + 3, PC = STRIDE * (WS_TW - 1) + 3, P = PR * PC;
+    constexpr int RB = CIN * 2, CH = CIN / 8;                         // bytes and 16-byte chunks per patch pixel
+    constexpr int KS16 = CIN / 16;                                     // k16 steps per tap
+    constexpr int NCHUNK = P * CH, ROUNDS = (NCHUNK + 255) / 256;
+    constexpr int BUF = ((P * RB + 255) / 256) * 256;
+    extern __shared__ __attribute__((aligned(256))) char smem_raw[];   // [2][BUF] patches | [NT * 32] scale | [NT * 32] shift
+    float* sstab = reinterpret_cast<float*>(smem_raw + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hl = lane >> 5, pl = lane & 31;
+
+    // ---- the filter bank, once
+    u32x4 wreg[NT][9 * KS16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int cs = 0; cs < KS16; ++cs) {
+                const int kt = (cs >> 1) * 9 + tap, sh = cs & 1;
+                wreg[nt][tap * KS16 + cs] = *reinterpret_cast<const u32x4*>(p.wf + ((size_t)nt * p.KT + kt) * 1024 + sh * 512 + lane * 8);
+            }
+    if (tid < NT * 32) {
+        const int c = tid < p.Cout ? tid : p.Cout - 1;
+        sstab[tid] = tid < p.Cout ? p.scale[c] : 0.f;
+        sstab[NT * 32 + tid] = tid < p.Cout ? p.shift[c] : 0.f;
+    }
+
+    auto swz = [](int pp) { return CH == 4 ? (pp >> 2) & 3 : (pp >> 1) & 7; };
+    // request the patch of tile t into buffer b: ROUNDS wave-instructions of 64 x 16 bytes, lane-linear in LDS
+    auto request = [&](int t, char* dst) {
+        const int img = fdiv(t, p.mg_tpi, p.tiles_per_img), rem = t - img * p.tiles_per_img;
+        const int th = fdiv(rem, p.mg_tw, p.tiles_w), tw = rem - th * p.tiles_w;
+        const int hi0 = th * WS_TH * STRIDE - 1, wi0 = tw * WS_TW * STRIDE - 1;
+        const unsigned short* zp = reinterpret_cast<const unsigned short*>(g_zero_page) + (lane & 7) * 8;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = r * 256 + tid;
+            if (idx < NCHUNK) {
+                const int pp = idx / CH, sl = idx - pp * CH;
+                const int pr = pp / PC, pc = pp - pr * PC;
+                const int hi = hi0 + pr, wi = wi0 + pc;
+                const bool ok = (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+                const unsigned short* src = p.x + ((size_t)(img * p.Hin + hi) * p.Win + wi) * p.x_ld + p.x_off + ((sl ^ swz(pp)) * 8);
+                glds16(ok ? src : zp, dst + (r * 256 + wave * 64) * 16);
+            }
+        }
+    };
+
+    // this lane's output pixel inside a tile, and its patch pixel for tap (0, 0)
+    const int r_o = 2 * wave + (pl >> 4), c_o = pl & 15;
+    const int p0 = (r_o * STRIDE) * PC + c_o * STRIDE;
+    const int stride_t = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= p.total_tiles) return;
+    request(t, smem_raw);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool saw_nan = false;
+    for (int it = 0; t < p.total_tiles; t += stride_t, ++it) {
+        char* cur = smem_raw + (it & 1) * BUF;
+        if (t + stride_t < p.total_tiles) request(t + stride_t, smem_raw + ((it + 1) & 1) * BUF);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int pp = p0 + (tap / 3) * PC + (tap % 3);
+            const int f = swz(pp);
+            const char* row = cur + pp * RB;
+#pragma unroll
+            for (int cs = 0; cs < KS16; ++cs) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(row + (((cs * 2 + hl) ^ f) << 4));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = HTraits<T>::mfma(__builtin_bit_cast(vec, wreg[nt][tap * KS16 + cs]), __builtin_bit_cast(vec, a), acc[nt]);
+            }
+        }
+        // the next tile's patch has had the whole matrix phase to land; everybody is done reading `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- epilogue (registers -> 16-byte stores), overlapping the next tile's request and matrix phase
+        const int img = fdiv(t, p.mg_tpi, p.tiles_per_img), rem = t - img * p.tiles_per_img;
+        const int th = fdiv(rem, p.mg_tw, p.tiles_w), tw = rem - th * p.tiles_w;
+        const int ho = th * WS_TH + r_o, wo = tw * WS_TW + c_o;
+        const bool live = ho < p.Ho && wo < p.Wo;
+        const size_t m = ((size_t)img * p.Ho + (live ? ho : 0)) * p.Wo + (live ? wo : 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(sstab + nt * 32 + 8 * g + 4 * hl);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(sstab + NT * 32 + nt * 32 + 8 * g + 4 * hl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = act_c<ACT>(acc[nt][4 * g + e] * sc[e] + sf[e]);
+            }
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * kp + e]), __float_as_uint(v[8 * kp + 4 + e]), false, false);
+                    w[e] = __uint_as_float(sw[0]);
+                    w[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int ch = nt * 32 + kp * 16 + 8 * hl;
+                const bool ok = live && ch < p.Cout;
+                if (RES && ok) {
+                    const u32x4 r4 = *reinterpret_cast<const u32x4*>(p.res + m * p.r_ld + p.r_off + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w[2 * e] += HTraits<T>::to_f32((unsigned short)(r4[e] & 0xffffu));
+                        w[2 * e + 1] += HTraits<T>::to_f32((unsigned short)(r4[e] >> 16));
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    saw_nan |= __builtin_isunordered(w[2 * e], w[2 * e + 1]);
+                    o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
+                }
+                if (ok) *reinterpret_cast<u32x4*>(p.y + m * p.y_ld + p.y_off + ch) = o;
+            }
+        }
+    }
+    if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
+}
+
+static bool ws_eligible(const yolo_conv_desc* d, const void* residual) {
+    static const bool off = getenv("YOLO_NO_CONV3_WS") != nullptr;
+    if (d->tile != 14 && (off || d->tile != 0)) return false;
+    if (d->ksize != 3 || d->out_mode != YOLO_OUT_NHWC || d->dtype == YOLO_F32) return false;
+    const bool shape = (d->stride == 1 && ((d->cin == 32 && d->cout > 32 && d->cout <= 64) || (d->cin == 64 && d->cout <= 32))) ||
+                       (d->stride == 2 && d->cin == 32 && d->cout > 32 && d->cout <= 64);
+    if (!shape || d->cout % 8) return false;
+    if ((d->x_ld & 7) || (d->x_off & 7) || (d->y_ld & 7) || (d->y_off & 7)) return false;
+    if (residual && ((d->r_ld & 7) || (d->r_off & 7))) return false;
+    if (d->stride == 2 && ((d->h & 1) || (d->w & 1))) return false;
+    return true;
+}
+
+template <typename T, int CIN, int NT, int STRIDE>
+static int launch_ws(ConvWsArgs& a, hipStream_t s) {
+    constexpr int PR = STRIDE * (WS_TH - 1) + 3, PC = STRIDE * (WS_TW - 1) + 3;
+    constexpr int BUF = ((PR * PC * CIN * 2 + 255) / 256) * 256;
+    const size_t lds = 2 * (size_t)BUF + 2 * NT * 32 * sizeof(float);
+    const int grid = a.total_tiles < 512 ? a.total_tiles : 512;       // two persistent workgroups per CU
+    const bool res = a.flags & YOLO_FLAG_RESIDUAL;
+    auto go = [&](auto kern) -> int {
+        static LdsOnce once;
+        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), lds, "conv3_ws_h16")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+        return check_launch("conv3_ws_h16");
+    };
+    YOLO_SWITCH_ACT(a.act, return res ? go(&conv3_ws_h16<T, CIN, NT, STRIDE, ACT, true>) : go(&conv3_ws_h16<T, CIN, NT, STRIDE, ACT, false>));
+    return fail(YOLO_ERR_ARG, "conv3_ws_h16: activation");
+}
+
+static int conv_ws_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift, const void* residual,
+                          void* y, int32_t* nan_flag, hipStream_t s) {
+    ConvWsArgs a;
+    a.x = (const unsigned short*)x; a.wf = (const unsigned short*)wf; a.scale = scale; a.shift = shift;
+    a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.nan_flag = nan_flag;
+    a.N = d->n; a.Hin = d->h; a.Win = d->w;
+    a.Ho = (d->h + 2 - 3) / d->stride + 1; a.Wo = (d->w + 2 - 3) / d->stride + 1;
+    a.x_ld = d->x_ld; a.x_off = d->x_off; a.y_ld = d->y_ld; a.y_off = d->y_off; a.r_ld = d->r_ld; a.r_off = d->r_off;
+    a.Cout = d->cout; a.KT = (d->cin / 32) * 9; a.act = d->act; a.flags = d->flags;
+    a.tiles_w = ceil_div(a.Wo, WS_TW);
+    a.tiles_per_img = a.tiles_w * ceil_div(a.Ho, WS_TH);
+    const long long total = (long long)a.tiles_per_img * d->n;
+    if (total > 0x7fffffffLL || (long long)d->n * d->h * d->w > 0x7fffffffLL) return fail(YOLO_ERR_UNSUPPORTED, "conv3_ws_h16: too many pixels");
+    a.total_tiles = (int)total;
+    a.mg_tpi = magic_of(a.tiles_per_img); a.mg_tw = magic_of(a.tiles_w);
+    if ((a.flags & YOLO_FLAG_NANCHECK) && !nan_flag) return fail(YOLO_ERR_ARG, "conv3_ws_h16: nan_flag is NULL");
+    const bool bf = d->dtype == YOLO_BF16;
+    if (d->stride == 2) return bf ? launch_ws<__bf16, 32, 2, 2>(a, s) : launch_ws<_Float16, 32, 2, 2>(a, s);
+    if (d->cin == 32) return bf ? launch_ws<__bf16, 32, 2, 1>(a, s) : launch_ws<_Float16, 32, 2, 1>(a, s);
+    return bf ? launch_ws<__bf16, 64, 1, 1>(a, s) : launch_ws<_Float16, 64, 1, 1>(a, s);
+}
+
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s) {
     return conv_h16_launch_stats(d, x, wf, scale, shift, residual, y, nan_flag, nullptr, nullptr, nullptr, s, nullptr);
@@ -2641,6 +2859,8 @@ int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf
     // pixel tiles of 52x52 / 104x104 (its two 16-lane groups are quads {0,3,5,6} and {1,2,4,7}: 4 rows whose patch offsets collide
     // mod 16); sending even tile rows to one group and odd rows to the other removes that, and measured 1-4 % at every size
     // (profiles/r02/ab_quad_permutation.txt). Tile 10 keeps the identity map for A/B.
+    if (d->tile == 14 && !ws_eligible(d, residual)) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 14 needs a 3x3 32 -> 64 (stride 1 / 2) or 64 -> 32 (stride 1) layer, NHWC");
+    if (!want_stats && ws_eligible(d, residual)) return conv_ws_launch(d, x, wf, scale, shift, residual, y, nan_flag, s);
     a.qperm = d->tile == 10 ? 0x76543210u : 0x76452310u;
     a.cls_ph = (d->tile == 0 && g_h_dma_persist) ? 11 : d->tile;
     if (dma1_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma))) {
