@@ -974,7 +974,11 @@ WGRAD16_CASES = [  # cin, cout, k, stride, H, W, N, dz_ld
     (64, 32, 1, 1, 52, 52, 1, 32), (512, 64, 3, 1, 5, 5, 4, 64),
     # round 3, wgrad3_dma_h16 (3x3 stride 1, cin >= 32): several K slices with the XCD-aware workgroup map and a ragged last
     # slice; one dW tile with 16 slices; channel counts that are not multiples of the 64-wide tile or of 16
-    (128, 256, 3, 1, 52, 52, 4, 256), (64, 64, 3, 1, 104, 40, 2, 64), (40, 72, 3, 1, 9, 9, 3, 72), (96, 32, 3, 1, 17, 33, 5, 40)]
+    (128, 256, 3, 1, 52, 52, 4, 256), (64, 64, 3, 1, 104, 40, 2, 64), (40, 72, 3, 1, 9, 9, 3, 72), (96, 32, 3, 1, 17, 33, 5, 40),
+    # round 3, stem_wgrad_h16 (first block: <= 3 input channels in an 8-channel 16-bit buffer, <= 32 output channels, W % 16 == 0):
+    # every border, rows shorter than a batch of K steps, waves with ragged last batches, one input channel, 24 output channels
+    (3, 32, 3, 1, 32, 32, 2, 32), (3, 32, 3, 1, 7, 48, 3, 32), (1, 32, 3, 1, 16, 16, 1, 32), (3, 24, 3, 1, 20, 64, 2, 40),
+    (3, 32, 3, 1, 1, 16, 1, 32), (3, 32, 3, 1, 416, 416, 1, 32)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -989,6 +993,7 @@ def test_wgrad_16bit_kernel_vs_fp64(yt, case, dtype):
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     x = torch.from_numpy(rng.standard_normal((N, H, W, cin), dtype=np.float32)).to(tdt)
+    x_ld = 8 if cin <= 3 else cin                                   # the first block reads the 8-channel 16-bit input buffer
     dz = torch.zeros((N, Ho, Wo, dz_ld), dtype=tdt)
     dz[..., :cout] = torch.from_numpy(rng.standard_normal((N, Ho, Wo, cout), dtype=np.float32)).to(tdt)
     xw = x.double().permute(0, 3, 1, 2)
@@ -999,8 +1004,10 @@ def test_wgrad_16bit_kernel_vs_fp64(yt, case, dtype):
     lib = L.lib()
     ws = torch.empty(lib.yolo_wgrad_workspace_bytes(N, H, W, cin, cout, k, s, code), dtype=torch.uint8, device="cuda")
     dw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device="cuda")
-    xd, dzd = x.cuda(), dz.cuda()
-    L.check(lib.yolo_conv_wgrad(dzd.data_ptr(), dz_ld, 0, xd.data_ptr(), cin, 0, dw.data_ptr(), N, H, W, cin, cout, k, s, code,
+    xp = torch.zeros((N, H, W, x_ld), dtype=tdt)
+    xp[..., :cin] = x
+    xd, dzd = xp.cuda(), dz.cuda()
+    L.check(lib.yolo_conv_wgrad(dzd.data_ptr(), dz_ld, 0, xd.data_ptr(), x_ld, 0, dw.data_ptr(), N, H, W, cin, cout, k, s, code,
                                 ws.data_ptr(), ws.numel(), L.current_stream()), "wgrad")
     got = dw.cpu().double()
     err = float((got - want).abs().max() / want.abs().max())

@@ -208,6 +208,11 @@ int dgrad_s2_h16_launch(const void* dz, int dz_ld, int dz_off, const void* wf, c
                         int dx_ld, int dx_off, int n, int ho, int wo, int cin, int cout, int dtype, hipStream_t s);
 int conv_h16_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,
                     const void* residual, void* y, int32_t* nan_flag, hipStream_t s);
+// wgrad_stem_h16.hip: weight gradient of the first block (3x3 stride 1, <= 3 input channels, <= 32 output channels)
+bool wgrad_stem_eligible(int n, int h, int w, int cin, int cout, int ksize, int stride, int dz_ld, int dz_off, int x_ld, int x_off);
+size_t wgrad_stem_workspace(int n, int h, int w);
+int wgrad_stem_launch(const void* dz, int dz_ld, int dz_off, const void* x, int x_off, float* workspace, float* dw_oihw, int n, int h,
+                      int w, int cin, int cout, int dtype, hipStream_t s);
 // backward statistics of an input-gradient launch: the block that produced the convolution's input (see ConvHArgs::bz)
 struct ConvBStats { const void* z; int z_ld, z_off; const float* mean; const float* scale; const float* shift; int act; };
 int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift,

@@ -260,6 +260,10 @@ size_t yolo_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ks
         if (ksize == 3 && stride == 1) {
             const size_t nd = wgrad_dma_workspace(n, h, w, cin, cout);
             if (nd > need) need = nd;
+            if (cin <= 3 && cout <= 32 && (w & 15) == 0) {
+                const size_t nst = wgrad_stem_workspace(n, h, w);
+                if (nst > need) need = nst;
+            }
         }
     }
     return need;
@@ -285,6 +289,8 @@ int yolo_conv_wgrad(const void* dz, int dz_ld, int dz_off, const void* x, int x_
         return fail(YOLO_ERR_ARG, "wgrad: ld/off must be multiples of 4 and cover the padded channels");
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)cout * ksize * ksize * (cp / 4);            // float4 groups of the partial layout
+    if (dtype != YOLO_F32 && wgrad_stem_eligible(n, h, w, cin, cout, ksize, stride, dz_ld, dz_off, x_ld, x_off))
+        return wgrad_stem_launch(dz, dz_ld, dz_off, x, x_off, (float*)workspace, dw_oihw, n, h, w, cin, cout, dtype, s);
     if (dtype != YOLO_F32 && wgrad_dma_eligible(cin, cout, ksize, stride, dz_ld, dz_off, x_ld, x_off))
         return wgrad_dma_launch(dz, dz_ld, dz_off, x, x_ld, x_off, (float*)workspace, dw_oihw, n, h, w, cin, cout, dtype, s);
     if (dtype != YOLO_F32 && wgrad_h16_eligible(cin, cout, ksize, stride, dz_ld, dz_off, x_ld, x_off)) {
