@@ -144,7 +144,7 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
         "traffic_unit": ("HBM bytes per launch (PMC, conv_patch_f32<3,64> 128->256 @52x52); algorithmic 134.1e6" if fp32 else
                          "HBM bytes per launch (PMC, conv3_dma_h16 128->256 @52x52); algorithmic 67.1e6"),
         "kernel": ("conv_patch_f32 / conv_igemm_f32 (3x3 launches, v_mfma_f32_32x32x2_f32)" if fp32 else
-                   f"conv3_dma_h16 (stride-1 3x3) + conv_patch_h16 (stride-2 3x3), v_mfma_f32_32x32x16_{'f16' if dtype == 'fp16' else 'bf16'}"),
+                   f"conv3_dma_h16 (stride-1 3x3) + conv1_dma_h16 with gathered rows (stride-2 3x3) + conv3_ws_h16 (<= 64 channels), v_mfma_f32_32x32x16_{'f16' if dtype == 'fp16' else 'bf16'}"),
         "launches_per_step": int(is3.sum()), "avg_launch_us": round(t3 / int(is3.sum()) * 1e6, 2),
         "algorithmic_gflop_per_step": round(f3 / 1e9, 2),
         "all_conv_launches": {"achieved": round(fall / tall / 1e12, 2), "launches_per_step": len(flops),
