@@ -256,8 +256,8 @@ def _stable_order(major, minor, descending_minor):
 def calc_mAP(pred_boxes, true_boxes, iou_threshold=0.5, box_format="center", num_classes=20):
     """Drop-in for the reference's ``calc_mAP`` (utils.py:193-274): rows ``[image_id, cx, cy, w, h, obj, class]``
     (lists or tensors), returns the mean over the classes that have ground truth of the trapezoid area under the
-    precision/recall curve, as a 0-dim CPU tensor. The per-pair Python loop becomes two stable device sorts and
-    two kernels (sequential matching per class, AP integration)."""
+    precision/recall curve, as a 0-dim CPU tensor. The two stable list sorts become one device sort each
+    (``_stable_order``), the per-pair Python loop two kernels (sequential matching per class, AP integration)."""
     dev = torch.device("cuda")
     dets = torch.as_tensor(pred_boxes, dtype=torch.float32).reshape(-1, 7).to(dev)
     gts = torch.as_tensor(true_boxes, dtype=torch.float32).reshape(-1, 7).to(dev)
