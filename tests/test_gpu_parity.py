@@ -1817,6 +1817,54 @@ def test_small_channel_3x3_weights_in_registers(yt, case, dtype):
     assert int(flag.item()) == 2
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_small_channel_3x3_and_first_block_gradient_random_shapes(yt, seed):
+    """Random sizes for the two per-tile streaming kernels of round 3: conv3_ws_h16 (default tile) against an fp64 convolution,
+    and stem_wgrad_h16 against an fp64 weight gradient - odd heights, widths that are / are not multiples of the 16-pixel tile,
+    batches that leave the last persistent round ragged."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    g = torch.Generator().manual_seed(seed)
+    # --- conv3_ws_h16
+    B, stride = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+    H, W = int(rng.integers(2, 40)) * stride, int(rng.integers(2, 70)) * stride
+    cin, cout = (32, int(rng.integers(5, 9)) * 8) if (stride == 2 or rng.random() < 0.5) else (64, int(rng.integers(1, 5)) * 8)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn((B, H, W, cin), generator=g).bfloat16()
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, 3, L.BF16), dtype=torch.uint8, device=dev)
+    xd, wd, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)         # (named: a temporary's memory is recycled before the launch runs)
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, 3, L.BF16, st))
+    y = torch.zeros((B, Ho, Wo, cout), dtype=torch.bfloat16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    d = L.ConvDesc(n=B, h=H, w=W, cin=cin, cout=cout, ksize=3, stride=stride, x_ld=cin, x_off=0, y_ld=cout, y_off=0, r_ld=0, r_off=0, act=1,
+                   out_mode=L.OUT_NHWC, dtype=L.BF16, flags=L.FLAG_NANCHECK, tile=0)
+    L.check(lib.yolo_conv_fwd(d, xd.data_ptr(), wp.data_ptr(), scd.data_ptr(), shd.data_ptr(), 0, y.data_ptr(), flag.data_ptr(), st), "yolo_conv_fwd")
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.bfloat16().double(), stride=stride, padding=1)
+    ref = F.leaky_relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.1).permute(0, 2, 3, 1)
+    err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-2 and int(flag.item()) == 0, (B, H, W, cin, cout, stride, err)
+    # --- stem_wgrad_h16
+    N, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 50)), int(rng.integers(1, 9)) * 16
+    cin, cout = int(rng.integers(1, 4)), int(rng.integers(1, 5)) * 8
+    xs = torch.zeros((N, H, W, 8), dtype=torch.bfloat16)
+    xs[..., :cin] = torch.randn((N, H, W, cin), generator=g).bfloat16()
+    dz = torch.zeros((N, H, W, 32), dtype=torch.bfloat16)
+    dz[..., :cout] = torch.randn((N, H, W, cout), generator=g).bfloat16()
+    wz = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs[..., :cin].double().permute(0, 3, 1, 2), wz, padding=1).backward(dz[..., :cout].double().permute(0, 3, 1, 2))
+    ws = torch.empty(lib.yolo_wgrad_workspace_bytes(N, H, W, cin, cout, 3, 1, L.BF16), dtype=torch.uint8, device=dev)
+    dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+    dzd, xsd = dz.to(dev), xs.to(dev)
+    L.check(lib.yolo_conv_wgrad(dzd.data_ptr(), 32, 0, xsd.data_ptr(), 8, 0, dw.data_ptr(), N, H, W, cin, cout, 3, 1, L.BF16,
+                                ws.data_ptr(), ws.numel(), st), "wgrad")
+    err = float((dw.cpu().double() - wz.grad).abs().max() / wz.grad.abs().max())
+    assert err < 2e-5, (N, H, W, cin, cout, err)
+
+
 S2_DGRAD_CASES = [  # (B, Ho, cin, cout, residual, dz_ld, dx_ld, dx_off)
     (2, 13, 32, 64, False, 64, 32, 0),           # the stem's successor: four classes in ONE n tile; 338 dz pixels, ragged last tile
     (1, 26, 64, 128, True, 128, 64, 0),          # two n tiles, accumulate into the running gradient
