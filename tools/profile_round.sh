@@ -17,6 +17,8 @@ pmc)
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_dec_$c -o pmc -- $PY tools/decode_bench.py 0 > $O/pmc_dec_$c.txt 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_decwb_$c -o pmc -- $PY tools/decode_bench.py 1 > $O/pmc_decwb_$c.txt 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_wg_$c -o pmc -- $PY tools/wgrad_bench.py 3 > $O/pmc_wg_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_ws_$c -o pmc -- $PY tools/conv_bench.py --dtype bf16 --layer c208_3x3 --tile 14 --reps 8 > $O/pmc_ws_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_sw_$c -o pmc -- $PY tools/wgrad_bench.py stem > $O/pmc_sw_$c.txt 2>&1
   done
   mkdir -p profiles/$R $O/profiles_$R
   $PY tools/pmc_traffic.py profiles/$R \
@@ -30,7 +32,9 @@ pmc)
       decode3 decode3_kernel - $O/pmc_dec_FETCH_SIZE $O/pmc_dec_WRITE_SIZE \
       decode3_write_back decode3_kernel - $O/pmc_decwb_FETCH_SIZE $O/pmc_decwb_WRITE_SIZE \
       wgrad3_dma_h16 wgrad3_dma_h16 - $O/pmc_wg_FETCH_SIZE $O/pmc_wg_WRITE_SIZE \
-      wgrad_reduce_acc wgrad_reduce_acc - $O/pmc_wg_FETCH_SIZE $O/pmc_wg_WRITE_SIZE > $O/pmc_traffic_stdout.txt 2>&1 || true
+      wgrad_reduce_acc wgrad_reduce_acc - $O/pmc_wg_FETCH_SIZE $O/pmc_wg_WRITE_SIZE \
+      conv3_ws_h16 conv3_ws_h16 - $O/pmc_ws_FETCH_SIZE $O/pmc_ws_WRITE_SIZE \
+      stem_wgrad_h16 stem_wgrad_h16 - $O/pmc_sw_FETCH_SIZE $O/pmc_sw_WRITE_SIZE > $O/pmc_traffic_stdout.txt 2>&1 || true
   cp profiles/$R/pmc_traffic.json profiles/$R/pmc_traffic.txt $O/profiles_$R/ 2>/dev/null || true
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -o pmc -- $PY tools/conv_bench.py --dtype bf16 --layer c52_3x3,c26_3x3 --tile 0 --reps 8 > $O/pmc_sq.txt 2>&1 && $PY tools/pmc_sum.py $O/pmc_sq conv3 > $O/pmc_sq_summary.txt || echo "SQ pass failed" > $O/pmc_sq_summary.txt
   echo "pmc done";;
