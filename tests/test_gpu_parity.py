@@ -1309,6 +1309,48 @@ def test_bench_runs_over_rccl_with_one_rank(tmp_path):
     assert d["train"]["value"] > 0 and d["train"]["bf16_autocast"]["value"] > 0
 
 
+@pytest.mark.gpu
+def test_round3_kernels_agree_with_round2_paths():
+    """The same seeded bf16 fine-tune steps (Mish: smooth, so rounding differences stay small) in two child processes: every
+    round-3 kernel path on (default), and all of them switched off through their A/B environment switches (weight gradient on
+    LDS-DMA, stem weight gradient, gathered-row stride-2 forward / fused stride-2 input gradient, conv3_ws_h16, epilogue
+    BatchNorm statistics forward and backward, launch tables). Losses, loss parts, running statistics and the gradients of the
+    layers those kernels compute must agree to 16-bit rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    off = dict(YOLO_NO_WGRAD_DMA="1", YOLO_NO_STEM_WGRAD="1", YOLO_NO_S2_DMA="1", YOLO_NO_S2G="1", YOLO_NO_CONV3_WS="1",
+               YOLO_BN_FUSED_STATS="0", YOLO_BN_FUSED_BSTATS="0", YOLO_TRAIN_TAPE="0")
+    res = []
+    for extra in ({}, off, {"AB_FP32": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_step.py")], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b, f = res
+    # Two bf16 evaluations of a 75-layer network that round in different places differ by a few 1e-3 on the loss and by several
+    # per cent on loss parts that average a handful of cells; a wrong tap or a missing term is O(1). The yardstick is the fp32
+    # run of the same steps: the round-3 paths may not be further from it than round 2's paths (beyond noise), and the two 16-bit
+    # runs may not be further apart than their distance to fp32.
+    def dist(u, v):
+        return np.abs(np.asarray(u, dtype=np.float64) - np.asarray(v, dtype=np.float64))
+    for k in ("loss0", "loss1"):
+        da, db = abs(a[k] - f[k]), abs(b[k] - f[k])
+        assert da <= 1.5 * db + 2e-3 * abs(f[k]), (k, a[k], b[k], f[k])
+        assert abs(a[k] - b[k]) <= 1e-2 * abs(f[k]), (k, a[k], b[k], f[k])
+    pa, pb = dist(a["parts0"], f["parts0"]), dist(b["parts0"], f["parts0"])
+    assert float(pa.sum()) <= 1.5 * float(pb.sum()) + 2e-3 * float(np.sum(f["parts0"])), (a["parts0"], b["parts0"], f["parts0"])
+    np.testing.assert_allclose(a["rm0"], b["rm0"], rtol=1e-3, atol=1e-5)
+    for n, gf in f["grads"].items():
+        ga, gb = a["grads"][n], b["grads"][n]
+        da, db = abs(ga["norm"] - gf["norm"]), abs(gb["norm"] - gf["norm"])
+        assert da <= 1.5 * db + 2e-2 * gf["norm"], (n, ga["norm"], gb["norm"], gf["norm"])
+        ha, hb = dist(ga["head"], gf["head"]).max(), dist(gb["head"], gf["head"]).max()
+        assert ha <= 1.5 * hb + 0.05 * (np.abs(gf["head"]).max() + 1e-12) + 1e-3 * gf["norm"], (n, ga["head"], gb["head"], gf["head"])
+
+
 def test_train_mode_single_value_per_channel_is_rejected(yt):
     """nn.BatchNorm2d refuses batch statistics over one value (B = 1 at S = 32 leaves a 1x1 map): same ValueError."""
     m = yt.YOLOv3(num_classes=2).cuda().train()
