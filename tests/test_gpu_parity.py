@@ -1325,7 +1325,7 @@ def test_round3_kernels_agree_with_round2_paths():
                YOLO_BN_FUSED_STATS="0", YOLO_BN_FUSED_BSTATS="0", YOLO_TRAIN_TAPE="0")
     res = []
     for extra in ({}, off, {"AB_FP32": "1"}):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_step.py")], env=dict(os.environ, **extra), capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "ab_step.py")], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))

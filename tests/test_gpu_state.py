@@ -305,6 +305,6 @@ def test_rccl_all_reduce_inside_a_graph_capture_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, YOLO_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_graph_check.py")], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "dp_graph_check.py")], env=env, capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "DP_GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])

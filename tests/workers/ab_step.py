@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""One bf16 fine-tune step on seeded data; prints a JSON line with the loss, every per-scale loss part and the norms / a few
+"""(Test infrastructure: lives under tests/ because it uses the oracle's seeded input generators.)
+One bf16 fine-tune step on seeded data; prints a JSON line with the loss, every per-scale loss part and the norms / a few
 entries of selected gradients. Run it twice with different A/B environment switches (they are read once, at library load) and
 compare (AB_FP32=1: the same steps without autocast, the yardstick): tests/test_gpu_parity.py::test_round3_kernels_agree_with_round2_paths."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import yolo_for_turbines_amd as yt
 from tests import golden_inputs as gi

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""One-shot check of RCCL collectives inside a HIP-graph capture (run as a child process with YOLO_FORCE_DIST=1 and the torchrun
+"""(Test infrastructure: lives under tests/ because it uses the oracle's seeded input generators.)
+One-shot check of RCCL collectives inside a HIP-graph capture (run as a child process with YOLO_FORCE_DIST=1 and the torchrun
 environment of ONE rank): a data-parallel GraphedTrainStep (bucketed all-reduce captured) must walk the same parameter
 trajectory as eager data-parallel steps. Prints DP_GRAPH_OK on success."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import yolo_for_turbines_amd as yt
 from yolo_for_turbines_amd import dist as ydist

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: the golden fine-tune step on the GPU; per sampled parameter |ours - fp64| against |reference fp32 - fp64|
+"""(Test infrastructure: lives under tests/ because it uses the oracle's seeded input generators.)
+Diagnostic: the golden fine-tune step on the GPU; per sampled parameter |ours - fp64| against |reference fp32 - fp64|
 (tests/golden/train_step.npz = imported reference in fp32, train_step_fp64.npz = the same step in float64)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import yolo_for_turbines_amd as yt

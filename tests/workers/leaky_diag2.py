@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: per block of the golden fine-tune case, how far the train-mode forward activations are from a float64
+"""(Test infrastructure: lives under tests/ because it uses the oracle's seeded input generators.)
+Diagnostic: per block of the golden fine-tune case, how far the train-mode forward activations are from a float64
 run of the CPU oracle — ours (GPU fp32) next to the oracle's own fp32 run — and how many LeakyReLU branches differ."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import yolo_for_turbines_amd as yt

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: walk the 3-step reference trajectory (tests/golden/train_traj.npz) and print per-step deviations."""
+"""(Test infrastructure: lives under tests/ because it uses the oracle's seeded input generators.)
+Diagnostic: walk the 3-step reference trajectory (tests/golden/train_traj.npz) and print per-step deviations."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import yolo_for_turbines_amd as yt
 from oracle import net as onet
