@@ -1955,7 +1955,9 @@ def test_stride2_input_gradient_kernels(yt, case, dtype):
 
 FUSED_STATS_CASES = [  # B, H, cin, cout, k: 3x3 / 1x1 LDS-DMA kernels; ragged and image-straddling tiles, channel tiles with padding
     (2, 13, 64, 128, 3), (3, 7, 96, 72, 3), (1, 52, 128, 256, 3), (4, 26, 128, 136, 3), (2, 13, 256, 128, 1), (1, 19, 128, 200, 1),
-    (3, 5, 384, 128, 1)]
+    (3, 5, 384, 128, 1),
+    # conv3_ws_h16 (<= 64 channels; one row per wave of the persistent workgroups): [, stride]
+    (2, 20, 32, 64, 3), (1, 52, 64, 32, 3), (3, 9, 32, 40, 3), (2, 24, 32, 64, 3, 2), (1, 208, 32, 64, 3)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -1965,7 +1967,9 @@ def test_conv_epilogue_batchnorm_statistics(yt, case, dtype):
     against (a) the same convolution through yolo_conv_fwd: z bit-identical, and (b) yolo_bn_stats on that z and an fp64 mean /
     variance of the stored values: mean, invstd, scale, shift and the running-statistic update."""
     from yolo_for_turbines_amd import _lib as L
-    B, H, cin, cout, k = case
+    B, H, cin, cout, k = case[:5]
+    stride = case[5] if len(case) > 5 else 1
+    Ho = (H - 1) // stride + 1
     code, tdt = {"bf16": (L.BF16, torch.bfloat16), "fp16": (L.F16, torch.float16)}[dtype]
     g = torch.Generator().manual_seed(77 + cin + 3 * cout + H)
     lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
@@ -1973,14 +1977,14 @@ def test_conv_epilogue_batchnorm_statistics(yt, case, dtype):
     w = (torch.randn((cout, cin, k, k), generator=g) * (1.0 / (cin * k * k)) ** 0.5).to(dev)
     wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, k, code), dtype=torch.uint8, device=dev)
     L.check(lib.yolo_pack_weights(w.data_ptr(), wp.data_ptr(), cout, cin, k, code, st))
-    d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=1, x_ld=cin, x_off=0, y_ld=cout, y_off=0, r_ld=0, r_off=0, act=0,
+    d = L.ConvDesc(n=B, h=H, w=H, cin=cin, cout=cout, ksize=k, stride=stride, x_ld=cin, x_off=0, y_ld=cout, y_off=0, r_ld=0, r_off=0, act=0,
                    out_mode=L.OUT_NHWC, dtype=code, flags=0, tile=0)
     import ctypes as C
     ld = C.c_int(0)
     rows = lib.yolo_conv_stats_rows(d, C.byref(ld))
     assert rows > 0 and ld.value >= cout
     ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-    m = B * H * H
+    m = B * Ho * Ho
     z_ref = torch.full((m, cout), 7.0, dtype=tdt, device=dev)
     z = torch.full((m, cout), 7.0, dtype=tdt, device=dev)
     L.check(lib.yolo_conv_fwd(d, x.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z_ref.data_ptr(), 0, st), "conv")

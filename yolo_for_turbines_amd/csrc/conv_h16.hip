@@ -2611,9 +2611,15 @@ struct ConvWsArgs {
     int Cout, KT, act, flags;
     int tiles_w, tiles_per_img, total_tiles;
     unsigned mg_tpi, mg_tw;
+    float* stats;                         // STATS instances (train-mode forward): per-wave BatchNorm partial sums [row][2][stats_ld]
+    int stats_ld;
 };
 
-template <typename T, int CIN, int NT, int STRIDE, int ACT, bool RES>
+// STATS = true (ACT none, no residual): raw z AND the BatchNorm partial sums of the rounded values (d_epilogue_stats). A wave
+// keeps ONE running pair of sums per channel for all its tiles: per tile and 8-channel group the 32 pixel lanes of a half are
+// folded by the reduce-scatter butterfly of d_epilogue_bstats (16 live values) and the result is added into the wave's private
+// [2][32 NT] LDS accumulator with ds_add_f32 (one lane per address and tile: a fixed order); the accumulator is the wave's row.
+template <typename T, int CIN, int NT, int STRIDE, int ACT, bool RES, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
     typedef typename HTraits<T>::vec vec;
     constexpr int PR = STRIDE * (WS_TH - 1) + 3, PC = STRIDE * (WS_TW - 1) + 3, P = PR * PC;
@@ -2625,6 +2631,10 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
     float* sstab = reinterpret_cast<float*>(smem_raw + 2 * BUF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hl = lane >> 5, pl = lane & 31;
+    float* wsum = sstab + 2 * NT * 32 + wave * (2 * NT * 32);          // STATS: this wave's [2][NT * 32] sums
+    if (STATS) {
+        for (int i = lane; i < 2 * NT * 32; i += 64) wsum[i] = 0.f;
+    }
 
     // ---- the filter bank, once
     u32x4 wreg[NT][9 * KS16];
@@ -2637,7 +2647,7 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
                 const int kt = (cs >> 1) * 9 + tap, sh = cs & 1;
                 wreg[nt][tap * KS16 + cs] = *reinterpret_cast<const u32x4*>(p.wf + ((size_t)nt * p.KT + kt) * 1024 + sh * 512 + lane * 8);
             }
-    if (tid < NT * 32) {
+    if (!STATS && tid < NT * 32) {
         const int c = tid < p.Cout ? tid : p.Cout - 1;
         sstab[tid] = tid < p.Cout ? p.scale[c] : 0.f;
         sstab[NT * 32 + tid] = tid < p.Cout ? p.shift[c] : 0.f;
@@ -2713,7 +2723,7 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(sstab + nt * 32 + 8 * g + 4 * hl);
                 const f32x4 sf = *reinterpret_cast<const f32x4*>(sstab + NT * 32 + nt * 32 + 8 * g + 4 * hl);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = act_c<ACT>(acc[nt][4 * g + e] * sc[e] + sf[e]);
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = STATS ? acc[nt][4 * g + e] : act_c<ACT>(acc[nt][4 * g + e] * sc[e] + sf[e]);
             }
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
@@ -2741,10 +2751,57 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_h16(const ConvWsArgs p) {
                     o[e] = pack2<T>(w[2 * e], w[2 * e + 1]);
                 }
                 if (ok) *reinterpret_cast<u32x4*>(p.y + m * p.y_ld + p.y_off + ch) = o;
+                if constexpr (STATS) {
+                    const float lv = ok ? 1.f : 0.f;
+                    float sq[2][8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0 = HTraits<T>::to_f32((unsigned short)(o[e] & 0xffffu)) * lv;
+                        const float r1 = HTraits<T>::to_f32((unsigned short)(o[e] >> 16)) * lv;
+                        sq[0][2 * e] = r0; sq[0][2 * e + 1] = r1;
+                        sq[1][2 * e] = r0 * r0; sq[1][2 * e + 1] = r1 * r1;
+                    }
+                    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+                    float l8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq[0][e]), __float_as_uint(sq[1][e]), false, false);
+                        l8[e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    }
+                    float l4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t0 = l8[e] + dpp_f<0x140>(l8[e]);
+                        const float t1 = l8[e + 4] + dpp_f<0x140>(l8[e + 4]);
+                        l4[e] = b3 ? t1 : t0;
+                    }
+                    float l2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float t0 = l4[e] + dpp_f<0x141>(l4[e]);
+                        const float t1 = l4[e + 2] + dpp_f<0x141>(l4[e + 2]);
+                        l2[e] = b2 ? t1 : t0;
+                    }
+                    const float u0 = l2[0] + dpp_f<0x4E>(l2[0]);
+                    const float u1 = l2[1] + dpp_f<0x4E>(l2[1]);
+                    float l1 = b1 ? u1 : u0;
+                    l1 += dpp_f<0xB1>(l1);
+                    // lane: quantity (lane >> 4) & 1, channel nt * 32 + kp * 16 + 8 hl + 4 b3 + 2 b2 + b1; the odd lane of a pair is a duplicate
+                    if (!(lane & 1))
+                        atomicAdd(wsum + ((lane >> 4) & 1) * (NT * 32) + nt * 32 + kp * 16 + 8 * hl + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0), l1);
+                }
             }
         }
     }
     if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
+    if constexpr (STATS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row = blockIdx.x * 4 + wave;
+        for (int i = lane; i < 2 * NT * 32; i += 64) {
+            const int qty = i / (NT * 32), c = i - qty * (NT * 32);
+            p.stats[((size_t)row * 2 + qty) * p.stats_ld + c] = wsum[i];
+        }
+    }
 }
 
 static bool ws_eligible(const yolo_conv_desc* d, const void* residual) {
@@ -2760,12 +2817,14 @@ static bool ws_eligible(const yolo_conv_desc* d, const void* residual) {
     return true;
 }
 
+static int ws_grid(int total_tiles) { return total_tiles < 512 ? total_tiles : 512; }   // two persistent workgroups per CU
+
 template <typename T, int CIN, int NT, int STRIDE>
 static int launch_ws(ConvWsArgs& a, hipStream_t s) {
     constexpr int PR = STRIDE * (WS_TH - 1) + 3, PC = STRIDE * (WS_TW - 1) + 3;
     constexpr int BUF = ((PR * PC * CIN * 2 + 255) / 256) * 256;
-    const size_t lds = 2 * (size_t)BUF + 2 * NT * 32 * sizeof(float);
-    const int grid = a.total_tiles < 512 ? a.total_tiles : 512;       // two persistent workgroups per CU
+    const size_t lds = 2 * (size_t)BUF + (2 + 8) * NT * 32 * sizeof(float);     // patches | scale, shift | 4 waves x [2][NT * 32] sums
+    const int grid = ws_grid(a.total_tiles);
     const bool res = a.flags & YOLO_FLAG_RESIDUAL;
     auto go = [&](auto kern) -> int {
         static LdsOnce once;
@@ -2773,13 +2832,15 @@ static int launch_ws(ConvWsArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
         return check_launch("conv3_ws_h16");
     };
+    if (a.stats) return go(&conv3_ws_h16<T, CIN, NT, STRIDE, YOLO_ACT_NONE, false, true>);
     YOLO_SWITCH_ACT(a.act, return res ? go(&conv3_ws_h16<T, CIN, NT, STRIDE, ACT, true>) : go(&conv3_ws_h16<T, CIN, NT, STRIDE, ACT, false>));
     return fail(YOLO_ERR_ARG, "conv3_ws_h16: activation");
 }
 
 static int conv_ws_launch(const yolo_conv_desc* d, const void* x, const void* wf, const float* scale, const float* shift, const void* residual,
-                          void* y, int32_t* nan_flag, hipStream_t s) {
+                          void* y, int32_t* nan_flag, hipStream_t s, float* stats = nullptr, int stats_ld = 0) {
     ConvWsArgs a;
+    a.stats = stats; a.stats_ld = stats_ld;
     a.x = (const unsigned short*)x; a.wf = (const unsigned short*)wf; a.scale = scale; a.shift = shift;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.nan_flag = nan_flag;
     a.N = d->n; a.Hin = d->h; a.Win = d->w;
@@ -2861,6 +2922,17 @@ int conv_h16_launch_stats(const yolo_conv_desc* d, const void* x, const void* wf
     // (profiles/r02/ab_quad_permutation.txt). Tile 10 keeps the identity map for A/B.
     if (d->tile == 14 && !ws_eligible(d, residual)) return fail(YOLO_ERR_UNSUPPORTED, "conv (16-bit): tile 14 needs a 3x3 32 -> 64 (stride 1 / 2) or 64 -> 32 (stride 1) layer, NHWC");
     if (!want_stats && ws_eligible(d, residual)) return conv_ws_launch(d, x, wf, scale, shift, residual, y, nan_flag, s);
+    if (want_stats && !bs && ws_eligible(d, residual)) {            // train-mode forward of the <= 64-channel 3x3 blocks: one row per wave
+        const int ho = (d->h + 2 - 3) / d->stride + 1, wo = (d->w + 2 - 3) / d->stride + 1;
+        const long long total = (long long)ceil_div(wo, WS_TW) * ceil_div(ho, WS_TH) * d->n;
+        if (total <= 0x7fffffffLL) {
+            const int rows = 4 * ws_grid((int)total);
+            if (rows_ld) { rows_ld[0] = rows; rows_ld[1] = a.stats_ld; }
+            if (dry) return YOLO_OK;
+            if (stats_bytes && *stats_bytes < (size_t)rows * 2 * a.stats_ld * sizeof(float)) return fail(YOLO_ERR_WORKSPACE, "conv statistics: buffer too small");
+            return conv_ws_launch(d, x, wf, stats, stats, nullptr, y, nan_flag, s, stats, a.stats_ld);
+        }
+    }
     a.qperm = d->tile == 10 ? 0x76543210u : 0x76452310u;
     a.cls_ph = (d->tile == 0 && g_h_dma_persist) ? 11 : d->tile;
     if (dma1_ok && (d->tile == 8 || (d->tile == 0 && g_h_dma))) {
