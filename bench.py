@@ -487,11 +487,15 @@ def main():
                      ("torch.optim.SGD" if args.torch_sgd else "yt.SGD: one launch, same bits as torch.optim.SGD") + ")")
 
         def make_step(lf, autocast_dtype):              # train.py:41-69: zero_grad, autocast forward, 3 x loss, backward, SGD
+            # the reference's YOLOLoss overwrites its targets (loss.py:70) and train.py gets fresh ones from the loader every batch;
+            # this loop reuses one set, so that loss gets a copy per step. FusedYOLOLoss leaves its inputs alone: no copy
+            fresh = (lambda t: t.clone()) if isinstance(lf, yt.YOLOLoss) else (lambda t: t)
+
             def train_step():
                 opt.zero_grad(set_to_none=True)
                 with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
                     preds = tm(x)                       # the loss sits inside the autocast block, as in train.py:53-65
-                    loss = sum(sum(lf(preds[i], tg[i].clone(), sa[i])) for i in range(3))
+                    loss = sum(sum(lf(preds[i], fresh(tg[i]), sa[i])) for i in range(3))
                 loss.backward()
                 opt.step()
             return train_step
