@@ -66,6 +66,7 @@ typedef struct yolo_conv_desc {
 typedef struct yolo_conv_op {
     yolo_conv_desc d;
     uint64_t x, w_packed, scale, shift, residual, y;
+    uint64_t workspace, workspace_bytes;   /* yolo_conv_workspace_bytes(&d); 0 / 0 = none (direct kernels only) */
 } yolo_conv_op;
 
 const char* yolo_last_error(void);
@@ -77,7 +78,8 @@ int yolo_version(void);
  * K index = (kh*k + kw)*cin_pad + ci (channels innermost, matching NHWC gathers), used by the
  * register-staged kernel, and, when cin % 32 == 0, (2) a copy in MFMA-fragment order
  * [cout_pad128/32][cin/32][k*k][4][64 lanes][4] streamed straight into registers by the
- * stride-1 patch kernel. */
+ * stride-1 patch kernel, and, when ksize == 3 and cin % 4 == 0, (3) the Winograd-domain filters
+ * G g G^T as [16][cin/4][cout_pad64][4] (yolo_conv_fwd_ws). */
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize);
 /* bytes of the packed buffer for a dtype. YOLO_F16 / YOLO_BF16: fragment order for
  * v_mfma_f32_32x32x16_{f16,bf16}: [cout_pad128/32][cin/32][k*k][2][64 lanes][8 halfs] (cin % 32 == 0). */
@@ -120,6 +122,18 @@ int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scal
 int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                   const float* shift, const void* residual, void* y, int32_t* nan_flag, void* stream);
 int yolo_conv_fwd_batch(const yolo_conv_op* ops, int n_ops, int32_t* nan_flag, void* stream);
+/* The same block with a caller-owned workspace. The fp32 3x3 stride-1 blocks with >= 128 input channels (the second convolution
+ * of the residual units of model.py:115-121 at 52x52 / 26x26 / 13x13, the 3x3 layers of the neck and of ScalePredictionBlock
+ * model.py:140-143) then run as Winograd F(2x2, 3x3) - the algorithm PyTorch's backend itself picks for them: an input
+ * transform pass into the workspace (16 planes of the 4x4 tiles, [xi][cin/4][tile][4]), 16 matrix products on the
+ * transformed filters (third section of the packed fp32 buffer: [xi][cin/4][cout_pad64][4]) and the output transform in the
+ * epilogue; 1 / 2.25 of the direct convolution's multiplications, same result within a few ulp of the transforms'
+ * additions. yolo_conv_workspace_bytes: what descriptor d needs (0 = the launch takes no workspace); a NULL or smaller
+ * workspace makes tile 0 fall back to the direct kernels of yolo_conv_fwd, tile 13 (= Winograd, forced) fail.
+ * Streams that run concurrently need a workspace each. */
+size_t yolo_conv_workspace_bytes(const yolo_conv_desc* d);
+int yolo_conv_fwd_ws(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                     const void* residual, void* y, void* workspace, size_t workspace_bytes, int32_t* nan_flag, void* stream);
 /* tile id the heuristic would pick (exposed for tests / tuning) and number of tile ids */
 int yolo_conv_pick_tile(const yolo_conv_desc* d);
 int yolo_conv_num_tiles(void);

@@ -36,7 +36,7 @@ def test_header_symbols_exported(built):
 def test_struct_layout_matches_header(built):
     import ctypes as C
     assert C.sizeof(built.ConvDesc) == 18 * 4
-    assert C.sizeof(built.ConvOp) == 18 * 4 + 6 * 8
+    assert C.sizeof(built.ConvOp) == 18 * 4 + 8 * 8
     assert C.sizeof(built.Call) == 8 + 8 * built.CALL_MAX_ARGS and C.sizeof(built.Reloc) == 24      # yolo_call / yolo_reloc
     hdr = open(os.path.join(ROOT, "include", "yolo_mi355x.h")).read()
     enum = re.search(r"enum \{ (YOLO_FN_FILL_ZERO = 1[^}]*)\}", hdr).group(1)
@@ -46,6 +46,8 @@ def test_struct_layout_matches_header(built):
     assert built.lib().yolo_packed_weight_elems(255, 1024, 1) == 2 * 256 * 1024      # row-major + fragment-order copy
     assert built.lib().yolo_packed_weight_elems(32, 3, 3) == 128 * 64
     assert built.lib().yolo_packed_weight_elems(32, 3, 2) == 0
+    # 3x3 with cin % 4 == 0: + the Winograd-domain filters [16][cin/4][cout_pad64][4]
+    assert built.lib().yolo_packed_weight_elems(256, 128, 3) == 2 * 256 * 1152 + 16 * 128 * 256
 
 
 def test_argument_errors_are_reported(built):

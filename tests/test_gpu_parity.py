@@ -1734,6 +1734,85 @@ def test_fp32_1x1_register_stationary_kernel(yt, case):
     assert int(flag.item()) & 2
 
 
+WINO_CASES = [
+    # (B, H, W, cin, cout, residual, act, x_ld, x_off, y_ld, y_off, r_ld, r_off): conv_wino_f32 (fp32 3x3 stride 1, Winograd F(2x2, 3x3))
+    (2, 10, 10, 128, 256, True, 1, 128, 0, 256, 0, 256, 0),        # 50 tiles: one ragged tile block, four channel blocks, 32 stages
+    (2, 13, 13, 512, 1024, False, 1, 512, 0, 1024, 0, 0, 0),       # odd size: the last tile row / column writes one pixel; 128 stages
+    (3, 9, 7, 256, 512, True, 2, 256, 0, 512, 0, 512, 0),          # H != W, both odd, Mish + residual; 60 tiles
+    (1, 26, 26, 256, 128, False, 0, 384, 128, 384, 256, 0, 0),     # reads a slice of a concat buffer, writes into one; identity epilogue
+    (2, 6, 8, 128, 84, True, 1, 128, 0, 84, 0, 96, 8),             # cout not a multiple of 64 (two channel blocks, the second ragged); residual view
+    (1, 4, 4, 4, 64, False, 1, 4, 0, 64, 0, 0, 0),                 # one stage (cin = 4): prologue / tail branches of the ring
+    (1, 5, 6, 32, 64, False, 1, 32, 0, 64, 0, 0, 0),               # eight stages
+    (1, 8, 8, 64, 64, True, 1, 64, 0, 64, 0, 64, 0),               # sixteen stages
+    (9, 26, 26, 128, 64, False, 1, 128, 0, 64, 0, 0, 0),           # 1,521 tiles: 24 tile blocks over the 8 XCD lanes of the block map (three rounds)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_fp32_winograd_kernel(yt, case):
+    """conv_wino_f32 through the C-ABI (`yolo_conv_fwd_ws`, tile = 13): ragged tile / channel blocks, odd and non-square maps,
+    1-3 stage rings, ld / off views, residual, every activation; the rest of the output buffer untouched; NaN flag. Reference:
+    fp64 convolution of the same operands (model.py:80-86, 115-121) - the bar is what Winograd's transforms cost in fp32
+    (1e-5 of max|y|; the north-star bar is 1e-3). The direct kernel (tile 0 without a workspace) is checked beside it."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, W, cin, cout, residual, act, x_ld, x_off, y_ld, y_off, r_ld, r_off = case
+    g = torch.Generator().manual_seed(900 + cin + cout + H + W + B)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    x = torch.randn((B, H, W, x_ld), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (9 * cin)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    y0 = torch.randn((B, H, W, y_ld), generator=g)
+    r = torch.randn((B, H, W, r_ld), generator=g) if residual else None
+    xd, sd, shd, wd = x.to(dev), scale.to(dev), shift.to(dev), w.to(dev)
+    rd = r.to(dev) if residual else None
+    wp = torch.empty(lib.yolo_packed_weight_bytes(cout, cin, 3, L.F32), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights(wd.data_ptr(), wp.data_ptr(), cout, cin, 3, L.F32, st))
+    xin = x[..., x_off:x_off + cin].double().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.1) if act == 1 else (F.mish(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + r[..., r_off:r_off + cout].double()
+
+    def desc(tile):
+        return L.ConvDesc(n=B, h=H, w=W, cin=cin, cout=cout, ksize=3, stride=1, x_ld=x_ld, x_off=x_off, y_ld=y_ld, y_off=y_off,
+                          r_ld=r_ld, r_off=r_off, act=act, out_mode=L.OUT_NHWC, dtype=L.F32,
+                          flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
+    d = desc(13)
+    need = lib.yolo_conv_workspace_bytes(d)
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    assert need == (tiles + 63) // 64 * 64 * cin * 64
+    ws = torch.full((need + 64,), 0x7f, dtype=torch.uint8, device=dev)          # NaN-ish garbage: the transform pass must define all it reads
+    errs = {}
+    for tile, wsp, wsb in ((13, ws.data_ptr(), need), (0, 0, 0)):
+        yd = y0.clone().to(dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.yolo_conv_fwd_ws(desc(tile), xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                     yd.data_ptr(), wsp, wsb, flag.data_ptr(), st), "yolo_conv_fwd_ws")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        got = yd.cpu()
+        errs[tile] = float((got[..., y_off:y_off + cout].double() - ref).abs().max() / ref.abs().max())
+        keep = torch.ones(y_ld, dtype=torch.bool)
+        keep[y_off:y_off + cout] = False
+        assert torch.equal(got[..., keep], y0[..., keep])           # neighbouring channels of the buffer untouched
+    assert errs[13] <= 1e-5 and errs[0] <= 5e-6, errs
+    assert int(ws[need:].min()) == 0x7f                              # nothing written past the stated size
+    # too small a workspace: tile 13 refuses, tile 0 silently takes the direct kernel
+    yd = y0.clone().to(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.yolo_conv_fwd_ws(desc(13), xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                yd.data_ptr(), ws.data_ptr(), need - 16, flag.data_ptr(), st) == -4
+    # a NaN in the input reaches the flag
+    xn = xd.clone()
+    xn[0, 0, 0, x_off] = float("nan")
+    L.check(lib.yolo_conv_fwd_ws(d, xn.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
+                                 yd.data_ptr(), ws.data_ptr(), need, flag.data_ptr(), st), "yolo_conv_fwd_ws")
+    torch.cuda.synchronize()
+    assert int(flag.item()) & 2
+
+
 S2_CASES = [  # (B, H, cin, cout, residual, act, y_ld, y_off): 3x3 stride 2 on conv1_dma_h16 with gathered rows (tile 13)
     (2, 26, 64, 128, False, 1, 128, 0),          # KT = 18; 338 output pixels: three tiles, the last ragged
     (1, 52, 128, 256, False, 2, 256, 0),         # two n tiles

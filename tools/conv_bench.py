@@ -56,9 +56,12 @@ def run(name, batch, tile, reps, residual, dev, dtype="fp32"):
                    r_ld=cout, r_off=0, act=L.ACT_LEAKY, out_mode=L.OUT_NHWC, dtype=code,
                    flags=(L.FLAG_RESIDUAL if residual else 0) | L.FLAG_NANCHECK, tile=tile)
 
+    need = lib.yolo_conv_workspace_bytes(d)                       # > 0: Winograd (tile 13, or the heuristic's choice for tile 0)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+
     def launch():
-        L.check(lib.yolo_conv_fwd(d, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(r),
-                                  y.data_ptr(), flag.data_ptr(), stream), "conv")
+        L.check(lib.yolo_conv_fwd_ws(d, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(r),
+                                     y.data_ptr(), ws.data_ptr() if need else 0, need, flag.data_ptr(), stream), "conv")
     for _ in range(3):
         launch()
     torch.cuda.synchronize()

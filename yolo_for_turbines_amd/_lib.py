@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
 
 
 class ConvOp(C.Structure):
-    _fields_ = [("d", ConvDesc)] + [(n, C.c_uint64) for n in ("x", "w_packed", "scale", "shift", "residual", "y")]
+    _fields_ = [("d", ConvDesc)] + [(n, C.c_uint64) for n in ("x", "w_packed", "scale", "shift", "residual", "y",
+                                                              "workspace", "workspace_bytes")]
 
 
 CALL_MAX_ARGS = 24
@@ -86,6 +87,9 @@ _SIGS = {
     "yolo_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_conv_fwd_batch": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_void_p, C.c_void_p]),
+    "yolo_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "yolo_conv_fwd_ws": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "yolo_conv_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "yolo_conv_num_tiles": (C.c_int, []),
     "yolo_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -196,6 +196,15 @@ int conv_v2_launch(const yolo_conv_desc* d, const void* x, const float* wf, cons
 bool conv1_rs_eligible(const yolo_conv_desc* d, const void* residual);
 int conv1_rs_launch(const yolo_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                     void* y, int32_t* nan_flag, hipStream_t s);
+// conv_wino_f32.hip (fp32 3x3 stride 1 by Winograd F(2x2, 3x3): transform pass into a caller-owned workspace + 16 GEMMs with
+// the output transform in the epilogue). U sits behind the fragment-order copy in the packed fp32 buffer.
+size_t wino_weight_elems(int cout, int cin, int ks);
+int wino_pack(const float* w_oihw, float* U, int cout, int cin, hipStream_t s);
+bool wino_supported(const yolo_conv_desc* d);
+bool wino_eligible(const yolo_conv_desc* d);
+size_t wino_workspace_bytes(const yolo_conv_desc* d);
+int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, const float* scale, const float* shift,
+                     const void* residual, void* y, void* workspace, size_t workspace_bytes, int32_t* nan_flag, hipStream_t s);
 // conv_h16.hip (bf16 / fp16 patch kernel)
 size_t h16_frag_elems(int cout, int cin, int ks);
 int h16_pack(const float* w_oihw, void* wf, int cout, int cin, int ks, int dtype, hipStream_t s);

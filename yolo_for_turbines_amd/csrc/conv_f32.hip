@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 
 
 constexpr int kNumTiles = 10;     // 1-4: register-staged tiles above; 5/6: conv_f32_v2.hip with BN = 64/128; 7: BN = 64, one patch buffer (3 blocks/CU); 8-10: 16-bit only (conv3_dma_h16)
+constexpr int kTileRs = 12;       // conv1_rs_f32.hip (fp32 1x1, weights in registers)
+constexpr int kTileWino = 13;     // conv_wino_f32.hip (fp32 3x3 stride 1, Winograd F(2x2, 3x3); needs the caller's workspace)
 constexpr int kMaxTileId = 31;    // ids above kNumTiles select timing probes of the diagnostic library (make probes); the product library runs tile 8 for them
 
 static size_t lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * LDS_LD * sizeof(float); }
@@ -288,7 +290,13 @@ static int launch_tile(const ConvArgs& a, bool smallc, hipStream_t s) {
 // Measured on MI355X (tools/conv_bench.py, batch 32). The register-staged kernel of this file is
 // latency-bound, so among its tiles 64x64 (4+ resident blocks per CU) wins on every YOLOv3 shape;
 // stride-1 layers with cin % 32 == 0 go to the patch/fragment-stream kernel (ids 5, 6).
+static int pick_direct_tile(const yolo_conv_desc* d);
 static int pick_tile(const yolo_conv_desc* d) {
+    if (wino_eligible(d)) return kTileWino;         // with a workspace (yolo_conv_fwd_ws / the launch table); without one: the ids below
+    return pick_direct_tile(d);
+}
+
+static int pick_direct_tile(const yolo_conv_desc* d) {
     if (v2_eligible(d) && d->ksize == 3) {
         // Measured (tools/conv_bench.py --tile 5,6,7, batch 32): BN = 64 with ONE patch buffer (tile 7: 37 KB of LDS,
         // 148 registers -> 3 blocks per CU instead of 2, one extra barrier per 32-channel chunk) wins by 4-16 % at 208x208,
@@ -317,7 +325,7 @@ static int validate(const yolo_conv_desc* d) {
 }
 
 static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
-                         const void* residual, void* y, int32_t* nan_flag, hipStream_t s) {
+                         const void* residual, void* y, void* ws, size_t ws_bytes, int32_t* nan_flag, hipStream_t s) {
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !w || !scale || !shift || !y) return fail(YOLO_ERR_ARG, "conv: null pointer");
@@ -343,9 +351,16 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     const bool smallc = a.Cin == 4;
     // 1x1 with 256 / 384 / 512 input channels and a multiple of 128 output channels: weights stationary in registers (tile 0 =
     // heuristic, or tile 12 explicitly; tiles 1-4 keep the register-staged kernel for A/B)
-    if ((d->tile == 0 || d->tile == 12) && conv1_rs_eligible(d, residual)) return conv1_rs_launch(d, x, w, scale, shift, residual, y, nan_flag, s);
-    if (d->tile == 12) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 12 needs a 1x1 with 256 / 384 / 512 input channels and cout %% 128 == 0");
-    const int t = d->tile ? d->tile : pick_tile(d);
+    if ((d->tile == 0 || d->tile == kTileRs) && conv1_rs_eligible(d, residual)) return conv1_rs_launch(d, x, w, scale, shift, residual, y, nan_flag, s);
+    if (d->tile == kTileRs) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 12 needs a 1x1 with 256 / 384 / 512 input channels and cout %% 128 == 0");
+    // 3x3 stride 1 by Winograd F(2x2, 3x3): tile 13 explicitly, or the heuristic when the caller brought a large enough workspace
+    // (yolo_conv_fwd itself has none: the library allocates nothing)
+    if (d->tile == kTileWino || (d->tile == 0 && wino_eligible(d) && ws && ws_bytes >= wino_workspace_bytes(d))) {
+        if (!wino_supported(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 13 needs fp32 3x3 stride 1 with NHWC output and channel counts %% 4 == 0");
+        const float* U = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize) + v2_frag_elems(d->cout, d->cin, d->ksize);
+        return conv_wino_launch(d, x, U, scale, shift, residual, y, ws, ws_bytes, nan_flag, s);
+    }
+    const int t = d->tile ? d->tile : pick_direct_tile(d);
     if (t >= 8) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile ids from 8 up are 16-bit kernels (conv3_dma_h16)");
     if (t >= 5) {
         if (!v2_eligible(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile %d needs stride 1 and cin %% 32 == 0", t);
@@ -374,7 +389,18 @@ int yolo_conv_pick_tile(const yolo_conv_desc* d) {
 
 int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                   const void* residual, void* y, int32_t* nan_flag, void* stream) {
-    return yolo::conv_fwd_impl(d, x, w_packed, scale, shift, residual, y, nan_flag, (hipStream_t)stream);
+    return yolo::conv_fwd_impl(d, x, w_packed, scale, shift, residual, y, nullptr, 0, nan_flag, (hipStream_t)stream);
+}
+
+size_t yolo_conv_workspace_bytes(const yolo_conv_desc* d) {
+    if (yolo::validate(d)) return 0;
+    if (d->tile == yolo::kTileWino || (d->tile == 0 && yolo::wino_eligible(d))) return yolo::wino_workspace_bytes(d);
+    return 0;
+}
+
+int yolo_conv_fwd_ws(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                     const void* residual, void* y, void* workspace, size_t workspace_bytes, int32_t* nan_flag, void* stream) {
+    return yolo::conv_fwd_impl(d, x, w_packed, scale, shift, residual, y, workspace, workspace_bytes, nan_flag, (hipStream_t)stream);
 }
 
 int yolo_conv_fwd_batch(const yolo_conv_op* ops, int n_ops, int32_t* nan_flag, void* stream) {
@@ -382,8 +408,8 @@ int yolo_conv_fwd_batch(const yolo_conv_op* ops, int n_ops, int32_t* nan_flag, v
     for (int i = 0; i < n_ops; ++i) {
         const yolo_conv_op& o = ops[i];
         int rc = yolo::conv_fwd_impl(&o.d, (const void*)o.x, (const void*)o.w_packed, (const float*)o.scale,
-                                     (const float*)o.shift, (const void*)o.residual, (void*)o.y, nan_flag,
-                                     (hipStream_t)stream);
+                                     (const float*)o.shift, (const void*)o.residual, (void*)o.y, (void*)o.workspace,
+                                     (size_t)o.workspace_bytes, nan_flag, (hipStream_t)stream);
         if (rc) return rc;
     }
     return YOLO_OK;

@@ -1,0 +1,438 @@
+// conv_wino_f32.hip — the fp32 3x3 stride-1 blocks (model.py:80-86 with kernel_size = 3: the second convolution of every
+// residual unit model.py:115-121, the 3x3 layers of the neck and of ScalePredictionBlock model.py:140-143) by the Winograd
+// minimal-filtering algorithm F(2x2, 3x3):
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A            per 4x4 input tile d, 3x3 filter g, 2x2 output tile Y
+//
+// 16 multiplications per 4 outputs and (ci, co) pair instead of 36: the matrix cores do 1 / 2.25 of the direct
+// convolution's work. conv_patch_f32 (the direct implicit GEMM) sits at 0.72-0.77 of the f32 matrix peak and its ceiling
+// at the clock the chip holds under it is ~0.86 - the fp32 forward could only get faster by doing fewer
+// multiplications. This is the algorithm the reference's own backend picks for these layers (PyTorch -> MIOpen / cuDNN
+// Winograd for fp32 3x3 stride 1), exact in exact arithmetic; in fp32 the transforms add a few ulp (B^T and A^T hold only
+// 0 / +-1, G only 0 / +-1/2 / 1): measured against the oracle in tests/test_gpu_parity.py, bar 1e-3 (BASELINE north_star).
+//
+// Three kernels:
+//   wino_pack_f32    U[xi][ci/4][co_pad64][4] = (G g G^T)[xi], xi = 4a + b, once per weight version (fp64 sums, one rounding);
+//   wino_xform_f32   V[xi][ci/4][tile_pad64][4] = (B^T d B)[xi] for every 4x4 input tile (stride 2, zero padding 1):
+//                    a thread owns one (tile, 4 channels); lanes run along tiles, so every store instruction of a wave
+//                    is 1 KiB contiguous; reads are 16 bytes per lane from 16 pixels (lines shared through L1 / L2);
+//   conv_wino_f32    per workgroup 64 tiles x 64 output channels x all 16 xi: 16 independent GEMMs
+//                    D_xi[co][tile] = sum_ci U_xi[co][ci] V_xi[tile][ci] on v_mfma_f32_32x32x2_f32, then the output
+//                    transform A^T D A, scale / shift / activation / residual and 16-byte stores from registers.
+//
+// conv_wino_f32 in detail (one 256-thread workgroup per CU, one wave per SIMD):
+//   * wave (wm, wn) owns 32 tiles x 32 channels x 16 xi = 16 accumulator blocks of 16 registers = 256 accumulator
+//     registers (the AGPR half of a lone wave's 512). Every lane therefore holds ALL 16 xi of its (tile, 16 channels):
+//     the output transform is 24 additions per output quad inside the lane, no cross-lane or LDS exchange.
+//   * U is the MFMA's A operand, V its B operand: D = [channel][tile]; a lane owns one tile and four runs of four
+//     consecutive channels -> float4 stores / residual loads; the four runs of a pixel are one 128-byte line.
+//   * both operands by LDS-DMA (global_load_lds_dwordx4) in stages of 4 input channels: a stage is 16 xi x 64 rows x 16 B
+//     for V and the same for U = 32 KiB, every wave-instruction 1 KiB contiguous on both sides (that is what the
+//     [xi][ci/4][row][4] layouts are for); ring of 4 stages, two in flight beyond the one being multiplied.
+//   * a lane reads its fragments with ds_read_b64: channels 2h, 2h+1 of its row (h = lane >> 5) = the k of two MFMAs;
+//     a wave's read is 512 contiguous bytes (conflict-free). 32 reads feed 32 MFMAs (2,048 matrix cycles) per stage.
+//   * ONE barrier per stage, placed after the 12th of the 16 xi: behind it come the DMA requests of stage i + 3 and the first
+//     fragment reads of stage i + 1, then the last four xi of stage i - the barrier's skew and the LDS latency of the
+//     next stage hide behind 8 MFMAs (512 cycles) instead of draining the matrix pipe once per stage.
+//   * blockIdx -> (tile block, channel block) so that the channel blocks of one tile block run back to back on ONE XCD
+//     (blockIdx % 8 = XCD): V is fetched into that L2 once; U (2-34 MB) is shared by everybody.
+// Arithmetic: an f32 MFMA chain is a k-ordered fmaf chain per xi; results differ from the direct kernel's by the
+// transforms' roundings only. An image's result does not depend on its batch (tiles are independent, the choice of
+// kernel looks at cin / h / w only).
+#include <type_traits>
+#include "common.h"
+
+namespace yolo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+typedef const __attribute__((address_space(1))) void* wn_gptr;
+typedef __attribute__((address_space(3))) void* wn_lptr;
+__device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((wn_gptr)g, (wn_lptr)l, 16, 0, 0); }
+template <int N> __device__ __forceinline__ void wn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// fragments of one xi: the U row (A operand) and the V row (B operand), channels 2h and 2h + 1 of the stage
+template <int OFF>
+__device__ __forceinline__ void wn_read2(f32x2& a, f32x2& b, unsigned ua, unsigned va) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(a) : "v"(ua), "n"(OFF));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b) : "v"(va), "n"(OFF));
+}
+
+template <int I, int N, class Fn>
+__device__ __forceinline__ void wn_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        wn_for<I + 1, N>(fn);
+    }
+}
+
+// ------------------------------------------------------------------------------ weights: U = G g G^T
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+__global__ void wino_pack_f32(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int coutp, long long total) {
+    const int C4 = cin / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const long long r0 = i >> 2;
+        const int co = (int)(r0 % coutp);
+        const long long r1 = r0 / coutp;
+        const int c4 = (int)(r1 % C4);
+        const int xi = (int)(r1 / C4);
+        float out = 0.f;
+        if (co < cout) {
+            const float* g = w + ((size_t)co * cin + 4 * c4 + e) * 9;
+            const int a = xi >> 2, b = xi & 3;
+            double t[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double g0 = g[q], g1 = g[3 + q], g2 = g[6 + q];
+                t[q] = a == 0 ? g0 : a == 1 ? 0.5 * (g0 + g1 + g2) : a == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+            }
+            const double u = b == 0 ? t[0] : b == 1 ? 0.5 * (t[0] + t[1] + t[2]) : b == 2 ? 0.5 * (t[0] - t[1] + t[2]) : t[2];
+            out = (float)u;
+        }
+        U[i] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------ input transform: V = B^T d B
+struct WinoXArgs {
+    const float* x;
+    float* V;
+    int H, W, C4;
+    int x_ld, x_off;
+    int th, tw, T, Tpad;
+};
+
+// B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+__global__ __launch_bounds__(256) void wino_xform_f32(const WinoXArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 4 + wave;
+    const int t = blockIdx.y * 64 + lane;
+    if (c4 >= p.C4) return;
+    const bool tv = t < p.T;
+    const int tt = tv ? t : 0;
+    const int per = p.th * p.tw;
+    const int n = tt / per, rem = tt - n * per;
+    const int ty = rem / p.tw, tx = rem - ty * p.tw;
+    const int r0 = 2 * ty - 1, c0 = 2 * tx - 1;
+    const float* base = p.x + p.x_off + 4 * c4;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i;
+        const bool rv = tv && r >= 0 && r < p.H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const bool v = rv && c >= 0 && c < p.W;
+            const size_t pix = v ? ((size_t)n * p.H + r) * p.W + c : 0;
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(base + pix * p.x_ld);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            d[i][j] = v ? ld : z;
+        }
+    }
+    // rows: r = B^T d
+    f32x4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = d[0][j] - d[2][j];
+        r[1][j] = d[1][j] + d[2][j];
+        r[2][j] = d[2][j] - d[1][j];
+        r[3][j] = d[1][j] - d[3][j];
+    }
+    float* dst = p.V + ((size_t)c4 * p.Tpad + t) * 4;
+    const size_t xs = (size_t)p.C4 * p.Tpad * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const f32x4 v0 = r[a][0] - r[a][2];
+        const f32x4 v1 = r[a][1] + r[a][2];
+        const f32x4 v2 = r[a][2] - r[a][1];
+        const f32x4 v3 = r[a][1] - r[a][3];
+        *reinterpret_cast<f32x4*>(dst + (4 * a + 0) * xs) = v0;
+        *reinterpret_cast<f32x4*>(dst + (4 * a + 1) * xs) = v1;
+        *reinterpret_cast<f32x4*>(dst + (4 * a + 2) * xs) = v2;
+        *reinterpret_cast<f32x4*>(dst + (4 * a + 3) * xs) = v3;
+    }
+}
+
+// ------------------------------------------------------------------------------ 16 GEMMs + output transform + block epilogue
+struct WinoArgs {
+    const float* V;
+    const float* U;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int* nan_flag;
+    int T, Tpad, C4, Cout, CoutPad;
+    int th, tw, H, W;
+    int y_ld, y_off, r_ld, r_off;
+    int flags;
+    int n_mt, n_nt;
+};
+
+constexpr int WN_STAGE = 32768;          // bytes per ring stage: V [16][64][4] floats, then U [16][64][4]
+constexpr int WN_SLOTS = 4;
+constexpr int WN_DMA = 8;                // DMA wave-instructions per wave and stage
+constexpr int WN_AHEAD = 4;              // fragment reads kept in flight, in xi (2 reads each)
+constexpr int WN_BAR = 16 - WN_AHEAD;    // the stage's barrier sits in front of this xi (all reads of the stage are issued by then)
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt = q % p.n_nt, mt = (q / p.n_nt) * 8 + xcd;
+    if (mt >= p.n_mt) return;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // ---- DMA roles: this wave moves xi = 4 wave .. 4 wave + 3 of V and of U, lane = row
+    const size_t v_xi = (size_t)p.C4 * p.Tpad * 4, v_c4 = (size_t)p.Tpad * 4;
+    const size_t u_xi = (size_t)p.C4 * p.CoutPad * 4, u_c4 = (size_t)p.CoutPad * 4;
+    const float* vsrc = p.V + (size_t)(4 * wave) * v_xi + ((size_t)mt * 64 + lane) * 4;
+    const float* usrc = p.U + (size_t)(4 * wave) * u_xi + ((size_t)nt * 64 + lane) * 4;
+    auto issue = [&](int c4, int slot) {
+        char* dst = smem + slot * WN_STAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn_glds16(vsrc + i * v_xi + c4 * v_c4, dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn_glds16(usrc + i * u_xi + c4 * u_c4, dst + 16384 + i * 1024);
+    };
+
+    // ---- fragment addresses: row 32 wm + m of V (B operand), row 32 wn + m of U (A operand), channels 2h, 2h + 1
+    const unsigned lds0 = (unsigned)(size_t)(wn_lptr)smem;
+    const unsigned vb = lds0 + (32 * wm + m) * 16 + h * 8;
+    const unsigned ub = lds0 + 16384 + (32 * wn + m) * 16 + h * 8;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    f32x2 fa[16], fb[16];                 // U / V fragments of the stage being multiplied (the first WN_AHEAD also of the next)
+
+    const int nst = p.C4;
+    issue(0, 0);
+    if (nst > 1) issue(1, 1);
+    if (nst > 2) issue(2, 2);
+    if (nst > 2) wn_wait_vmcnt<2 * WN_DMA>();
+    else if (nst > 1) wn_wait_vmcnt<WN_DMA>();
+    else wn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    wn_for<0, WN_AHEAD>([&](auto X) { constexpr int x = decltype(X)::value; wn_read2<x * 1024>(fa[x], fb[x], ub, vb); });
+
+    int slot = 0;
+    for (int st = 0; st < nst; ++st) {
+        const unsigned sb = (unsigned)slot * WN_STAGE;
+        int ns = slot + 1;
+        ns = ns == WN_SLOTS ? 0 : ns;
+        const unsigned nb = (unsigned)ns * WN_STAGE;
+        wn_for<0, 16>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            static_assert(WN_AHEAD == 4, "the tail schedule below is written for four xi of look-ahead");
+            if constexpr (x == WN_BAR) {
+                // stage st + 1 has to be in LDS for everybody before its first fragments are read; the slot of stage st - 1
+                // (= of stage st + 3) is free once everybody is here
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 2 < nst) wn_wait_vmcnt<WN_DMA>();
+                else wn_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (x + WN_AHEAD < 16) wn_read2<(x + WN_AHEAD) * 1024>(fa[x + WN_AHEAD], fb[x + WN_AHEAD], ub + sb, vb + sb);
+            // reads issued after those of xi = x and still in flight (LDS operations return in order): 2 per xi. Behind the
+            // barrier: xi 12 -> 13, 14, 15; 13 -> 14, 15; 14 -> 15 and the next stage's 0, 1; 15 -> the next stage's 0 .. 3
+            constexpr int after = x < WN_BAR ? 2 * WN_AHEAD : x == 12 ? 6 : x == 13 ? 4 : x == 14 ? 6 : 8;
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][1], fb[x][1], acc[x], 0, 0, 0);
+            // the requests of stage st + 3 and the first reads of stage st + 1 go BETWEEN the last four xi: each pair of MFMAs
+            // covers 128 cycles of issue
+            if constexpr (x == WN_BAR) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 3 < nst) {
+                    int s3 = slot + 3;
+                    s3 = s3 >= WN_SLOTS ? s3 - WN_SLOTS : s3;
+                    issue(st + 3, s3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (x == WN_BAR + 1 || x == WN_BAR + 2) {
+                constexpr int y = 2 * (x - WN_BAR - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                wn_read2<y * 1024>(fa[y], fb[y], ub + nb, vb + nb);
+                wn_read2<(y + 1) * 1024>(fa[y + 1], fb[y + 1], ub + nb, vb + nb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        slot = ns;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the stage after the last
+
+    // ------------------------------------------------------------------ output transform + epilogue through LDS
+    // A^T = [1 1 1 0; 0 1 -1 -1]. From registers a lane would store 16 bytes of 16 different pixels per instruction (32-byte pieces
+    // of 32 lines: measured ~20 us per workgroup for 64 KiB out + 64 KiB of residual, as much as 20 stages of matrix work). So the
+    // activated tile goes through the idle ring as [4 pixels of a tile][64 tiles][64 channels + 4] and comes back with 16 lanes
+    // per pixel row: stores and residual loads are 256-byte runs.
+    constexpr int OLD = 68;
+    float* ost = reinterpret_cast<float*>(smem);
+    int* tab = reinterpret_cast<int*>(smem + 256 * OLD * 4);        // [64] first output pixel of the tile, [64] flags
+    __syncthreads();                                                  // every wave is done with the ring (no DMA is in flight)
+    if (tid < 64) {
+        const int t = mt * 64 + tid;
+        const bool tv = t < p.T;
+        const int tt = tv ? t : 0;
+        const int per = p.th * p.tw;
+        const int n = tt / per, rem = tt - n * per;
+        const int ty = rem / p.tw, tx = rem - ty * p.tw;
+        tab[tid] = (n * p.H + 2 * ty) * p.W + 2 * tx;
+        tab[64 + tid] = (tv ? 1 : 0) | (2 * tx + 1 < p.W ? 2 : 0) | (2 * ty + 1 < p.H ? 4 : 0);
+    }
+    __syncthreads();
+    // this thread's 16 rows of the staged tile: pixel pp = it / 4 of tile (tid / 16) + 16 (it % 4), channels 4 (tid % 16) ..
+    const int c16 = tid & 15;
+    const int co_t = nt * 64 + 4 * c16;
+    const bool cv = co_t < p.Cout;
+    int pix[16];
+    bool pv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int tl = (tid >> 4) + 16 * (it & 3), pp = it >> 2;
+        const int fl = tab[64 + tl];
+        pv[it] = cv && (fl & 1) && (!(pp & 1) || (fl & 2)) && (!(pp & 2) || (fl & 4));
+        pix[it] = pv[it] ? tab[tl] + (pp & 1) + (pp >> 1) * p.W : 0;
+    }
+    f32x4 rr[16];
+    if (RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            rr[it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix[it] * p.r_ld + p.r_off + (cv ? co_t : 0));
+    }
+    {
+        const int cob = 32 * wn + 4 * h;                              // channel inside the block: + 8 g + e
+        float* dst = ost + (32 * wm + m) * OLD + cob;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = nt * 64 + cob + 8 * g;
+            const int cc = co < p.Cout ? co : 0;                      // (cout is a multiple of 4: a run is valid or not as a whole)
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + cc);
+            f32x4 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float tr[2][4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    tr[0][b] = acc[b][r] + acc[4 + b][r] + acc[8 + b][r];
+                    tr[1][b] = acc[4 + b][r] - acc[8 + b][r] - acc[12 + b][r];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float y0 = tr[i][0] + tr[i][1] + tr[i][2];
+                    const float y1 = tr[i][1] - tr[i][2] - tr[i][3];
+                    o[2 * i][e] = act_c<ACT>(y0 * sc[e] + sh[e]);
+                    o[2 * i + 1][e] = act_c<ACT>(y1 * sc[e] + sh[e]);
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) *reinterpret_cast<f32x4*>(dst + pp * 64 * OLD + 8 * g) = o[pp];
+        }
+    }
+    __syncthreads();
+    bool saw_nan = false;
+    f32x4 va[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) va[it] = *reinterpret_cast<const f32x4*>(ost + ((tid >> 4) + 16 * it) * OLD + 4 * c16);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        f32x4 v = va[it];
+        if (RES) v += rr[it];
+        if (pv[it]) {
+            saw_nan |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
+            *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = v;
+        }
+    }
+    if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
+}
+
+// ------------------------------------------------------------------------------ host side
+static const bool g_wino_off = getenv("YOLO_NO_WINOGRAD") != nullptr;     // A/B switch: the direct kernels
+
+size_t wino_weight_elems(int cout, int cin, int ks) {
+    if (ks != 3 || cin % 4) return 0;
+    return (size_t)16 * (cin / 4) * round_up(cout, 64) * 4;
+}
+
+int wino_pack(const float* w_oihw, float* U, int cout, int cin, hipStream_t s) {
+    const long long total = (long long)wino_weight_elems(cout, cin, 3);
+    if (!total) return fail(YOLO_ERR_ARG, "wino_pack: cin %% 4");
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wino_pack_f32, dim3(grid), dim3(256), 0, s, w_oihw, U, cout, cin, round_up(cout, 64), total);
+    return check_launch("wino_pack_f32");
+}
+
+// what the kernels can run at all (tile 13 forces it on anything that passes)
+bool wino_supported(const yolo_conv_desc* d) {
+    if (d->dtype != YOLO_F32 || d->ksize != 3 || d->stride != 1 || d->out_mode != YOLO_OUT_NHWC) return false;
+    if (d->cin % 4 || d->cout % 4) return false;
+    if ((d->x_ld & 3) || (d->x_off & 3) || (d->y_ld & 3) || (d->y_off & 3)) return false;
+    if ((d->flags & YOLO_FLAG_RESIDUAL) && ((d->r_ld & 3) || (d->r_off & 3))) return false;
+    const long long T = (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2);
+    if (T + 64 > 0x7fffffffLL / 4 || (long long)d->n * d->h * d->w > 0x7fffffffLL) return false;
+    return true;
+}
+
+// the heuristic: where the 16 GEMMs are long enough to pay for the transform pass and the 4x larger operand stream.
+// Looks at the layer's shape only, never at the batch size (an image's result may not depend on its neighbours).
+bool wino_eligible(const yolo_conv_desc* d) {
+    if (g_wino_off || !wino_supported(d)) return false;
+    return d->cin >= 128 && d->cout >= 64;
+}
+
+size_t wino_workspace_bytes(const yolo_conv_desc* d) {
+    if (!wino_supported(d)) return 0;
+    const long long T = (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2);
+    return (size_t)round_up((int)T, 64) * d->cin * 16 * sizeof(float);
+}
+
+int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, const float* scale, const float* shift,
+                     const void* residual, void* y, void* workspace, size_t workspace_bytes, int32_t* nan_flag, hipStream_t s) {
+    if (!wino_supported(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv winograd: needs fp32 3x3 stride 1, NHWC output, channels %% 4 == 0");
+    const size_t need = wino_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) return fail(YOLO_ERR_WORKSPACE, "conv winograd: workspace %zu < %zu bytes", workspace_bytes, need);
+    if ((size_t)workspace & 15) return fail(YOLO_ERR_ARG, "conv winograd: workspace must be 16-byte aligned");
+    const int th = (d->h + 1) / 2, tw = (d->w + 1) / 2;
+    const int T = d->n * th * tw, Tpad = round_up(T, 64), C4 = d->cin / 4;
+    WinoXArgs xa;
+    xa.x = (const float*)x; xa.V = (float*)workspace; xa.H = d->h; xa.W = d->w; xa.C4 = C4; xa.x_ld = d->x_ld; xa.x_off = d->x_off;
+    xa.th = th; xa.tw = tw; xa.T = T; xa.Tpad = Tpad;
+    hipLaunchKernelGGL(wino_xform_f32, dim3(ceil_div(C4, 4), Tpad / 64), dim3(256), 0, s, xa);
+    if (int rc = check_launch("wino_xform_f32")) return rc;
+
+    WinoArgs a;
+    a.V = (const float*)workspace; a.U = U; a.scale = scale; a.shift = shift; a.res = (const float*)residual; a.y = (float*)y;
+    a.nan_flag = nan_flag;
+    a.T = T; a.Tpad = Tpad; a.C4 = C4; a.Cout = d->cout; a.CoutPad = round_up(d->cout, 64);
+    a.th = th; a.tw = tw; a.H = d->h; a.W = d->w;
+    a.y_ld = d->y_ld; a.y_off = d->y_off; a.r_ld = d->r_ld; a.r_off = d->r_off; a.flags = d->flags;
+    a.n_mt = Tpad / 64; a.n_nt = a.CoutPad / 64;
+    const int grid = 8 * a.n_nt * ceil_div(a.n_mt, 8);
+    const size_t lds = (size_t)WN_SLOTS * WN_STAGE;
+    const bool res = d->flags & YOLO_FLAG_RESIDUAL;
+    auto go = [&](auto kern) -> int {
+        static LdsOnce once;
+        if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), lds, "conv_wino_f32")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+        return check_launch("conv_wino_f32");
+    };
+    YOLO_SWITCH_ACT(d->act, return res ? go(&conv_wino_f32<ACT, true>) : go(&conv_wino_f32<ACT, false>));
+    return fail(YOLO_ERR_ARG, "conv winograd: activation");
+}
+
+}  // namespace yolo

@@ -170,14 +170,14 @@ int yolo_version(void) { return 100; }
 
 size_t yolo_packed_weight_bytes(int cout, int cin, int ksize, int dtype) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    if (dtype == YOLO_F32) return (v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize)) * sizeof(float);
+    if (dtype == YOLO_F32) return yolo_packed_weight_elems(cout, cin, ksize) * sizeof(float);
     if (dtype == YOLO_F16 || dtype == YOLO_BF16) return cin % 32 ? 0 : h16_frag_elems(cout, cin, ksize) * 2;
     return 0;
 }
 
 size_t yolo_packed_weight_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    return v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize);
+    return v0_packed_elems(cout, cin, ksize) + v2_frag_elems(cout, cin, ksize) + wino_weight_elems(cout, cin, ksize);
 }
 
 int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int dtype, void* stream) {
@@ -193,8 +193,11 @@ int yolo_pack_weights(const float* w_oihw, void* w_packed, int cout, int cin, in
     hipLaunchKernelGGL(pack_weights_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)w_packed, cout, cin,
                        ksize, cin_pad_of(cin), kpad_of(cin, ksize), total);
     int rc = check_launch("pack_weights");
-    if (rc || !v2_frag_elems(cout, cin, ksize)) return rc;
-    return v2_pack(w_oihw, (float*)w_packed + total, cout, cin, ksize, (hipStream_t)stream);
+    if (rc) return rc;
+    const size_t frag = v2_frag_elems(cout, cin, ksize);
+    if (frag && (rc = v2_pack(w_oihw, (float*)w_packed + total, cout, cin, ksize, (hipStream_t)stream))) return rc;
+    if (wino_weight_elems(cout, cin, ksize)) return wino_pack(w_oihw, (float*)w_packed + total + frag, cout, cin, (hipStream_t)stream);
+    return YOLO_OK;
 }
 
 int yolo_pack_weights_batch(const yolo_pack_item* items, int n, int dgrad, int dtype, void* stream) {

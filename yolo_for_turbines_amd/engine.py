@@ -352,6 +352,16 @@ class Plan:
                 self.stem_pk = pk
             if op["pred"] is not None:
                 self.pred_ops[op["pred"]] = (i, op["Ho"], blk.conv.out_channels // 3)
+        # one workspace for the launches that take one (fp32 3x3 stride 1 -> Winograd, yolo_conv_fwd_ws): the table runs on one
+        # stream, so the largest request serves them all
+        lib = L.lib()
+        need = [lib.yolo_conv_workspace_bytes(C.byref(self.table[i].d)) if i >= self.first else 0 for i in range(n_ops)]
+        self.workspace = torch.empty(max(need), dtype=torch.uint8, device=device) if n_ops and max(need) else None
+        if self.workspace is not None:
+            self.total_bytes += self.workspace.numel()
+            for i, nb in enumerate(need):
+                if nb:
+                    self.table[i].workspace, self.table[i].workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
         self.blocks0 = self.blocks[:1]    # the stem block alone (its own freshness check, see ModelState.forward)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.dropped = False
