@@ -103,8 +103,8 @@ def per_launch_times(plan, reps, x):
                 plan.load_input(x, stream)
             else:
                 e = plan.table[i]
-                L.check(lib.yolo_conv_fwd(e.d, e.x, e.w_packed, e.scale, e.shift, e.residual, e.y,
-                                          plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd")
+                L.check(lib.yolo_conv_fwd_ws(e.d, e.x, e.w_packed, e.scale, e.shift, e.residual, e.y, e.workspace, e.workspace_bytes,
+                                             plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd_ws")
             evs[i + 1].record()
         torch.cuda.synchronize()
         acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
@@ -128,6 +128,12 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
     fall, tall = float(np.sum(flops)), float(np.sum(times_ms)) * 1e-3
     ach = f3 / t3 / 1e12
     fp32 = dtype == "fp32"
+    # launches that run as Winograd F(2x2, 3x3) (conv_wino_f32: input-transform pass + 16 GEMMs + output transform): the
+    # algorithm multiplies 16 / 36 of the direct convolution's products, so its ALGORITHMIC flops are the direct ones / 2.25
+    from yolo_for_turbines_amd import _lib as L
+    isw = np.array([i >= plan.first and L.lib().yolo_conv_workspace_bytes(plan.table[i].d) > 0 for i in range(len(flops))])
+    if fp32 and isw.any():
+        return wino_roofline(plan, flops, times_ms, is3, isw, args, elapsed, gflop_img)
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_H16_MFMA_TFLOPS
     at_cfg1 = args.batch == 32 and args.size == 416
     out = {
@@ -152,6 +158,47 @@ def conv_roofline(model, x, dtype, args, elapsed, gflop_img):
         "whole_step_tflops": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
     }
     return out
+
+
+def wino_roofline(plan, flops, times_ms, is3, isw, args, elapsed, gflop_img):
+    """fp32 forward with the Winograd launches: `achieved` of the dominant kernel is priced on the flops the algorithm executes
+    (direct / 2.25), over the whole launch pair (transform pass + GEMM kernel), so `frac` stays a matrix-core utilisation
+    <= 1; the direct-convolution-equivalent rate (what the layer is worth to a caller) and the remaining direct launches
+    (stride 2, <= 64 input channels: conv_patch_f32 / conv_igemm_f32) are listed beside it."""
+    fl, t = np.array(flops), times_ms * 1e-3
+    fw_direct, tw = float(fl[isw].sum()), float(t[isw].sum())
+    fw_alg = fw_direct / 2.25
+    isd = is3 & ~isw
+    fd, td = float(fl[isd].sum()), float(t[isd].sum())
+    fall, tall = float(fl.sum()), float(t.sum())
+    executed_all = fall - fw_direct + fw_alg
+    at_cfg1 = args.batch == 32 and args.size == 416
+    tr = PMC_TRAFFIC.get("conv_wino_f32", (None, ""))
+    return {
+        "bound": "mfma", "achieved": round(fw_alg / tw / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(fw_alg / tw / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "kernel": "conv_wino_f32 (+ wino_xform_f32): fp32 3x3 stride 1 with >= 128 input channels as Winograd F(2x2,3x3), 16 GEMMs on "
+                  "v_mfma_f32_32x32x2_f32; time = both launches of a layer",
+        "algorithmic_flops": "Winograd-domain multiply-adds = direct-convolution flops / 2.25 (padding tiles of odd maps not counted)",
+        "launches_per_step": int(isw.sum()), "avg_launch_us": round(tw / int(isw.sum()) * 1e6, 2),
+        "algorithmic_gflop_per_step": round(fw_alg / 1e9, 2),
+        "direct_equivalent_tflops": round(fw_direct / tw / 1e12, 2),
+        "direct_equivalent_note": "the same launches priced at the direct convolution's 2*H*W*Cout*Cin*9 flops (may exceed the f32 matrix "
+                                  "peak: fewer multiplications, not faster matrix cores)",
+        "traffic": tr[0] if at_cfg1 else None,
+        "traffic_source": tr[1] or "no PMC pass of conv_wino_f32 committed yet",
+        "traffic_unit": "HBM bytes per layer (PMC: wino_xform_f32 + conv_wino_f32, 128->256 @52x52); algorithmic 134.1e6 + 2 x 177.2e6 "
+                        "for the transformed tiles written and read once",
+        "direct_3x3_launches": {"kernel": "conv_patch_f32 / conv_igemm_f32 (stride 2, <= 64 input channels)", "launches_per_step": int(isd.sum()),
+                                "achieved": round(fd / td / 1e12, 2) if td else None,
+                                "frac": round(fd / td / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if td else None,
+                                "avg_launch_us": round(td / max(1, int(isd.sum())) * 1e6, 2)},
+        "all_conv_launches": {"achieved_executed": round(executed_all / tall / 1e12, 2), "direct_equivalent": round(fall / tall / 1e12, 2),
+                              "launches_per_step": len(flops), "sum_kernel_ms": round(tall * 1e3, 3),
+                              "gflop_per_step_direct": round(fall / 1e9, 2), "gflop_per_step_executed": round(executed_all / 1e9, 2)},
+        "whole_step_tflops_direct_equivalent": round(fall * args.steps / elapsed / 1e12, 2) if gflop_img else None,
+        "whole_step_tflops_executed": round(executed_all * args.steps / elapsed / 1e12, 2) if gflop_img else None,
+    }
 
 
 # HBM bytes per launch of the dominant kernels from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS round's

@@ -173,12 +173,16 @@ struct WinoArgs {
 };
 
 constexpr int WN_STAGE = 32768;          // bytes per ring stage: V [16][64][4] floats, then U [16][64][4]
-constexpr int WN_SLOTS = 4;
+constexpr int WN_SLOTS = 4;              // (a power of two: slot arithmetic by mask)
 constexpr int WN_DMA = 8;                // DMA wave-instructions per wave and stage
 constexpr int WN_AHEAD = 4;              // fragment reads kept in flight, in xi (2 reads each)
+#ifndef WN_DMA_MODE
+#define WN_DMA_MODE 0
+#endif
 constexpr int WN_BAR = 16 - WN_AHEAD;    // the stage's barrier sits in front of this xi (all reads of the stage are issued by then)
 
-template <int ACT, bool RES>
+// PROBE (diagnostic build only, garbage results): 1 = no stage barrier / DMA wait, 2 = no DMA requests in the loop, 4 = no fragment reads
+template <int ACT, bool RES, int PROBE = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,42 +192,63 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
     const int nt = q % p.n_nt, mt = (q / p.n_nt) * 8 + xcd;
     if (mt >= p.n_mt) return;
     const int wm = wave & 1, wn = wave >> 1;
+#ifdef WN_STAMPS   // diagnostic build (make wstamps): per-workgroup phase stamps into the buffer passed as nan_flag (tools/wino_stamps.py)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- DMA roles: this wave moves xi = 4 wave .. 4 wave + 3 of V and of U, lane = row
     const size_t v_xi = (size_t)p.C4 * p.Tpad * 4, v_c4 = (size_t)p.Tpad * 4;
     const size_t u_xi = (size_t)p.C4 * p.CoutPad * 4, u_c4 = (size_t)p.CoutPad * 4;
     const float* vsrc = p.V + (size_t)(4 * wave) * v_xi + ((size_t)mt * 64 + lane) * 4;
     const float* usrc = p.U + (size_t)(4 * wave) * u_xi + ((size_t)nt * 64 + lane) * 4;
-    auto issue = [&](int c4, int slot) {
+    // piece k of a stage: k < 4 -> xi = 4 wave + k of V, else xi = 4 wave + k - 4 of U
+    auto issue_piece = [&](auto K, int c4, int slot) {
+        constexpr int k = decltype(K)::value;
         char* dst = smem + slot * WN_STAGE + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wn_glds16(vsrc + i * v_xi + c4 * v_c4, dst + i * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wn_glds16(usrc + i * u_xi + c4 * u_c4, dst + 16384 + i * 1024);
+        if constexpr (k < 4) wn_glds16(vsrc + k * v_xi + c4 * v_c4, dst + k * 1024);
+        else wn_glds16(usrc + (k - 4) * u_xi + c4 * u_c4, dst + 16384 + (k - 4) * 1024);
     };
+    auto issue = [&](int c4, int slot) { wn_for<0, WN_DMA>([&](auto K) { issue_piece(K, c4, slot); }); };
 
     // ---- fragment addresses: row 32 wm + m of V (B operand), row 32 wn + m of U (A operand), channels 2h, 2h + 1
     const unsigned lds0 = (unsigned)(size_t)(wn_lptr)smem;
     const unsigned vb = lds0 + (32 * wm + m) * 16 + h * 8;
     const unsigned ub = lds0 + 16384 + (32 * wn + m) * 16 + h * 8;
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-
     f32x2 fa[16], fb[16];                 // U / V fragments of the stage being multiplied (the first WN_AHEAD also of the next)
 
+    // folded scale / shift of this lane's 16 output channels (32 wn + 8 g + 4 h + e): requested before the ring's first pieces,
+    // so that no load - and no wait for one - sits between the residual requests and the stores of the epilogue
+    f32x4 sc[4], sh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = nt * 64 + 32 * wn + 4 * h + 8 * g;
+        const int cc = co < p.Cout ? co : 0;                          // (cout is a multiple of 4: a run is valid or not as a whole)
+        sc[g] = *reinterpret_cast<const f32x4*>(p.scale + cc);
+        sh[g] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+    }
     const int nst = p.C4;
     issue(0, 0);
     if (nst > 1) issue(1, 1);
     if (nst > 2) issue(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[16];                       // zeroed while the first pieces are on their way
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) asm volatile("" : "+a"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
     if (nst > 2) wn_wait_vmcnt<2 * WN_DMA>();
     else if (nst > 1) wn_wait_vmcnt<WN_DMA>();
     else wn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef WN_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     wn_for<0, WN_AHEAD>([&](auto X) { constexpr int x = decltype(X)::value; wn_read2<x * 1024>(fa[x], fb[x], ub, vb); });
 
     int slot = 0;
@@ -232,6 +257,39 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
         int ns = slot + 1;
         ns = ns == WN_SLOTS ? 0 : ns;
         const unsigned nb = (unsigned)ns * WN_STAGE;
+        // Where the DMA requests of the ring go (WN_DMA_MODE; stage st + 3 takes the slot stage st - 1 had, free from this stage's
+        // barrier on). A request costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost") with
+        // ONE MFMA in flight behind it, and this kernel has one wave per SIMD: nobody else issues MFMAs meanwhile.
+        //   0: all eight behind the first xi after the barrier;  1: one behind every second xi (12, 14, then 0 .. 10 of the next stage);
+        //   2: as 1, between the two MFMAs of the xi;  3: one behind each of the eight MFMAs after the barrier
+        auto dma_at = [&](auto XX, auto HH) {
+            constexpr int x = decltype(XX)::value, half = decltype(HH)::value;
+            if constexpr (PROBE & 2) return;
+            if constexpr (WN_DMA_MODE == 0) {
+                if constexpr (x == WN_BAR && half == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 3 < nst) issue(st + 3, (slot + 3) & (WN_SLOTS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (WN_DMA_MODE == 3) {
+                if constexpr (x >= WN_BAR) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 3 < nst) issue_piece(std::integral_constant<int, 2 * (x - WN_BAR) + half>{}, st + 3, (slot + 3) & (WN_SLOTS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (half == (WN_DMA_MODE == 1 ? 1 : 0)) {
+                if constexpr (x == WN_BAR || x == WN_BAR + 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 3 < nst) issue_piece(std::integral_constant<int, (x - WN_BAR) / 2>{}, st + 3, (slot + 3) & (WN_SLOTS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (x < WN_BAR && x % 2 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st >= 1 && st + 2 < nst) issue_piece(std::integral_constant<int, 2 + x / 2>{}, st + 2, (slot + 2) & (WN_SLOTS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
         wn_for<0, 16>([&](auto X) {
             constexpr int x = decltype(X)::value;
             static_assert(WN_AHEAD == 4, "the tail schedule below is written for four xi of look-ahead");
@@ -239,40 +297,40 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
                 // stage st + 1 has to be in LDS for everybody before its first fragments are read; the slot of stage st - 1
                 // (= of stage st + 3) is free once everybody is here
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + 2 < nst) wn_wait_vmcnt<WN_DMA>();
-                else wn_wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (x + WN_AHEAD < 16) wn_read2<(x + WN_AHEAD) * 1024>(fa[x + WN_AHEAD], fb[x + WN_AHEAD], ub + sb, vb + sb);
-            // reads issued after those of xi = x and still in flight (LDS operations return in order): 2 per xi. Behind the
-            // barrier: xi 12 -> 13, 14, 15; 13 -> 14, 15; 14 -> 15 and the next stage's 0, 1; 15 -> the next stage's 0 .. 3
-            constexpr int after = x < WN_BAR ? 2 * WN_AHEAD : x == 12 ? 6 : x == 13 ? 4 : x == 14 ? 6 : 8;
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][1], fb[x][1], acc[x], 0, 0, 0);
-            // the requests of stage st + 3 and the first reads of stage st + 1 go BETWEEN the last four xi: each pair of MFMAs
-            // covers 128 cycles of issue
-            if constexpr (x == WN_BAR) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 3 < nst) {
-                    int s3 = slot + 3;
-                    s3 = s3 >= WN_SLOTS ? s3 - WN_SLOTS : s3;
-                    issue(st + 3, s3);
+                if constexpr (!(PROBE & 1)) {
+                    if (st + 2 < nst) wn_wait_vmcnt<WN_DMA>();
+                    else wn_wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (x + WN_AHEAD < 16 && !(PROBE & 4)) wn_read2<(x + WN_AHEAD) * 1024>(fa[x + WN_AHEAD], fb[x + WN_AHEAD], ub + sb, vb + sb);
+            // reads issued after those of xi = x and still in flight (LDS operations return in order): 2 per xi. Behind the
+            // barrier: xi 12 -> 13, 14, 15; 13 -> 14, 15; 14 -> 15 and the next stage's 0, 1; 15 -> the next stage's 0 .. 3
+            constexpr int after = x < WN_BAR ? 2 * WN_AHEAD : x == 12 ? 6 : x == 13 ? 4 : x == 14 ? 6 : 8;
+            if constexpr (!(PROBE & 4)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
+            else asm volatile("" : "+v"(fa[x]), "+v"(fb[x]));
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
+            dma_at(X, std::integral_constant<int, 0>{});
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][1], fb[x][1], acc[x], 0, 0, 0);
+            dma_at(X, std::integral_constant<int, 1>{});
             if constexpr (x == WN_BAR + 1 || x == WN_BAR + 2) {
                 constexpr int y = 2 * (x - WN_BAR - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                wn_read2<y * 1024>(fa[y], fb[y], ub + nb, vb + nb);
-                wn_read2<(y + 1) * 1024>(fa[y + 1], fb[y + 1], ub + nb, vb + nb);
+                if constexpr (!(PROBE & 4)) {
+                    wn_read2<y * 1024>(fa[y], fb[y], ub + nb, vb + nb);
+                    wn_read2<(y + 1) * 1024>(fa[y + 1], fb[y + 1], ub + nb, vb + nb);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
         slot = ns;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the stage after the last
+#ifdef WN_STAMPS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ------------------------------------------------------------------ output transform + epilogue through LDS
     // A^T = [1 1 1 0; 0 1 -1 -1]. From registers a lane would store 16 bytes of 16 different pixels per instruction (32-byte pieces
@@ -282,6 +340,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
     constexpr int OLD = 68;
     float* ost = reinterpret_cast<float*>(smem);
     int* tab = reinterpret_cast<int*>(smem + 256 * OLD * 4);        // [64] first output pixel of the tile, [64] flags
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(sc[g]), "+v"(sh[g]));      // the compiler's wait for them goes HERE: nothing is in flight
     __syncthreads();                                                  // every wave is done with the ring (no DMA is in flight)
     if (tid < 64) {
         const int t = mt * 64 + tid;
@@ -313,15 +373,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
         for (int it = 0; it < 16; ++it)
             rr[it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix[it] * p.r_ld + p.r_off + (cv ? co_t : 0));
     }
+    __builtin_amdgcn_sched_barrier(0);                                // all residual rows are requested before the transform starts
     {
         const int cob = 32 * wn + 4 * h;                              // channel inside the block: + 8 g + e
         float* dst = ost + (32 * wm + m) * OLD + cob;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int co = nt * 64 + cob + 8 * g;
-            const int cc = co < p.Cout ? co : 0;                      // (cout is a multiple of 4: a run is valid or not as a whole)
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + cc);
             f32x4 o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -336,8 +393,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
                 for (int i = 0; i < 2; ++i) {
                     const float y0 = tr[i][0] + tr[i][1] + tr[i][2];
                     const float y1 = tr[i][1] - tr[i][2] - tr[i][3];
-                    o[2 * i][e] = act_c<ACT>(y0 * sc[e] + sh[e]);
-                    o[2 * i + 1][e] = act_c<ACT>(y1 * sc[e] + sh[e]);
+                    o[2 * i][e] = act_c<ACT>(y0 * sc[g][e] + sh[g][e]);
+                    o[2 * i + 1][e] = act_c<ACT>(y1 * sc[g][e] + sh[g][e]);
                 }
             }
 #pragma unroll
@@ -358,7 +415,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
             *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = v;
         }
     }
+#ifdef WN_STAMPS
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.nan_flag) + (size_t)blockIdx.x * 6;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = hwid; d[5] = xcc;
+    }
+    (void)saw_nan;
+#else
     if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
+#endif
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -431,6 +501,16 @@ int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, con
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
         return check_launch("conv_wino_f32");
     };
+#ifdef WN_STAMPS
+    switch (d->tile >= 16 ? d->tile - 16 : 0) {          // timing probes: tile 16 + bits
+    case 1: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 1>);
+    case 2: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 2>);
+    case 3: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 3>);
+    case 4: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 4>);
+    case 7: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 7>);
+    default: break;
+    }
+#endif
     YOLO_SWITCH_ACT(d->act, return res ? go(&conv_wino_f32<ACT, true>) : go(&conv_wino_f32<ACT, false>));
     return fail(YOLO_ERR_ARG, "conv winograd: activation");
 }
