@@ -173,11 +173,12 @@ def wino_roofline(plan, flops, times_ms, is3, isw, args, elapsed, gflop_img):
     fall, tall = float(fl.sum()), float(t.sum())
     executed_all = fall - fw_direct + fw_alg
     at_cfg1 = args.batch == 32 and args.size == 416
-    tr = PMC_TRAFFIC.get("conv_wino_f32", (None, ""))
+    tg, tx = PMC_TRAFFIC.get("conv_wino_f32", (None, "")), PMC_TRAFFIC.get("wino_xform_f32", (None, ""))
+    tr = (tg[0] + tx[0], tg[1]) if tg[0] and tx[0] else (None, "")
     return {
         "bound": "mfma", "achieved": round(fw_alg / tw / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(fw_alg / tw / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-        "kernel": "conv_wino_f32 (+ wino_xform_f32): fp32 3x3 stride 1 with >= 128 input channels as Winograd F(2x2,3x3), 16 GEMMs on "
+        "kernel": "conv_wino_f32 (+ wino_xform_f32): fp32 3x3 stride 1 with >= 64 input channels as Winograd F(2x2,3x3), 16 GEMMs on "
                   "v_mfma_f32_32x32x2_f32; time = both launches of a layer",
         "algorithmic_flops": "Winograd-domain multiply-adds = direct-convolution flops / 2.25 (padding tiles of odd maps not counted)",
         "launches_per_step": int(isw.sum()), "avg_launch_us": round(tw / int(isw.sum()) * 1e6, 2),
@@ -189,7 +190,7 @@ def wino_roofline(plan, flops, times_ms, is3, isw, args, elapsed, gflop_img):
         "traffic_source": tr[1] or "no PMC pass of conv_wino_f32 committed yet",
         "traffic_unit": "HBM bytes per layer (PMC: wino_xform_f32 + conv_wino_f32, 128->256 @52x52); algorithmic 134.1e6 + 2 x 177.2e6 "
                         "for the transformed tiles written and read once",
-        "direct_3x3_launches": {"kernel": "conv_patch_f32 / conv_igemm_f32 (stride 2, <= 64 input channels)", "launches_per_step": int(isd.sum()),
+        "direct_3x3_launches": {"kernel": "conv_patch_f32 / conv_igemm_f32 (stride 2, 32 input channels)", "launches_per_step": int(isd.sum()),
                                 "achieved": round(fd / td / 1e12, 2) if td else None,
                                 "frac": round(fd / td / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if td else None,
                                 "avg_launch_us": round(td / max(1, int(isd.sum())) * 1e6, 2)},

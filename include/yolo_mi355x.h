@@ -122,8 +122,8 @@ int yolo_stem_fwd(const float* x_nchw, const float* w_k_major, const float* scal
 int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                   const float* shift, const void* residual, void* y, int32_t* nan_flag, void* stream);
 int yolo_conv_fwd_batch(const yolo_conv_op* ops, int n_ops, int32_t* nan_flag, void* stream);
-/* The same block with a caller-owned workspace. The fp32 3x3 stride-1 blocks with >= 128 input channels (the second convolution
- * of the residual units of model.py:115-121 at 52x52 / 26x26 / 13x13, the 3x3 layers of the neck and of ScalePredictionBlock
+/* The same block with a caller-owned workspace. The fp32 3x3 stride-1 blocks with >= 64 input channels (the second convolution
+ * of the residual units of model.py:115-121 at 104x104 ... 13x13, the 3x3 layers of the neck and of ScalePredictionBlock
  * model.py:140-143) then run as Winograd F(2x2, 3x3) - the algorithm PyTorch's backend itself picks for them: an input
  * transform pass into the workspace (16 planes of the 4x4 tiles, [xi][cin/4][tile][4]), 16 matrix products on the
  * transformed filters (third section of the packed fp32 buffer: [xi][cin/4][cout_pad64][4]) and the output transform in the

@@ -12,7 +12,10 @@ PY=$(command -v python3)
 for st in $STAGES; do case $st in
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/pmc_f32_$c -o pmc -- $PY tools/conv_bench.py --dtype fp32 --layer c52_3x3,c26_3x3 --tile 0 --reps 8 > $O/pmc_f32_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_f32_$c -o pmc -- $PY tools/conv_bench.py --dtype fp32 --layer c52_3x3 --tile 7 --reps 8 > $O/pmc_f32_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_f32b_$c -o pmc -- $PY tools/conv_bench.py --dtype fp32 --layer c26_3x3 --tile 6 --reps 8 > $O/pmc_f32b_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_wino_$c -o pmc -- $PY tools/conv_bench.py --dtype fp32 --layer c52_3x3 --tile 13 --residual --reps 8 > $O/pmc_wino_$c.txt 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_winob_$c -o pmc -- $PY tools/conv_bench.py --dtype fp32 --layer c26_3x3 --tile 13 --residual --reps 8 > $O/pmc_winob_$c.txt 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_h16_$c -o pmc -- $PY tools/conv_bench.py --dtype bf16 --layer c104_3x3,c52_3x3,c26_3x3,c13_3x3,c52_1x1 --tile 0 --reps 8 > $O/pmc_h16_$c.txt 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_dec_$c -o pmc -- $PY tools/decode_bench.py 0 > $O/pmc_dec_$c.txt 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_decwb_$c -o pmc -- $PY tools/decode_bench.py 1 > $O/pmc_decwb_$c.txt 2>&1
@@ -23,7 +26,11 @@ pmc)
   mkdir -p profiles/$R $O/profiles_$R
   $PY tools/pmc_traffic.py profiles/$R \
       conv_patch_f32 conv_patch_f32 692224 $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE \
-      conv_patch_f32_c26 conv_patch_f32 184320 $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE \
+      conv_patch_f32_c26 conv_patch_f32 184320 $O/pmc_f32b_FETCH_SIZE $O/pmc_f32b_WRITE_SIZE \
+      conv_wino_f32 conv_wino_f32 - $O/pmc_wino_FETCH_SIZE $O/pmc_wino_WRITE_SIZE \
+      wino_xform_f32 wino_xform_f32 - $O/pmc_wino_FETCH_SIZE $O/pmc_wino_WRITE_SIZE \
+      conv_wino_f32_c26 conv_wino_f32 - $O/pmc_winob_FETCH_SIZE $O/pmc_winob_WRITE_SIZE \
+      wino_xform_f32_c26 wino_xform_f32 - $O/pmc_winob_FETCH_SIZE $O/pmc_winob_WRITE_SIZE \
       conv3_dma_h16 conv3_dma_h16 346112 $O/pmc_h16_FETCH_SIZE $O/pmc_h16_WRITE_SIZE \
       conv3_dma_h16_c104 conv3_dma_h16 692224 $O/pmc_h16_FETCH_SIZE $O/pmc_h16_WRITE_SIZE \
       conv3_dma_h16_c26 conv3_dma_h16 184320 $O/pmc_h16_FETCH_SIZE $O/pmc_h16_WRITE_SIZE \

@@ -50,6 +50,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* wn_gptr;
 typedef __attribute__((address_space(3))) void* wn_lptr;
 __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((wn_gptr)g, (wn_lptr)l, 16, 0, 0); }
+// the same request with the source as wave-uniform base (SGPR pair) + 32-bit lane offset, the LDS destination (wave-uniform byte
+// address) through M0. Written out because inside the stage loop the compiler's strength reduction turns base + offset back
+// into one 64-bit vector add per request.
+__device__ __forceinline__ void wn_glds16_s(const void* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");      // (M0 is written here; the compiler re-loads it before every use of its own)
+}
 template <int N> __device__ __forceinline__ void wn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // fragments of one xi: the U row (A operand) and the V row (B operand), channels 2h and 2h + 1 of the stage
@@ -202,14 +209,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
     // ---- DMA roles: this wave moves xi = 4 wave .. 4 wave + 3 of V and of U, lane = row
     const size_t v_xi = (size_t)p.C4 * p.Tpad * 4, v_c4 = (size_t)p.Tpad * 4;
     const size_t u_xi = (size_t)p.C4 * p.CoutPad * 4, u_c4 = (size_t)p.CoutPad * 4;
-    const float* vsrc = p.V + (size_t)(4 * wave) * v_xi + ((size_t)mt * 64 + lane) * 4;
-    const float* usrc = p.U + (size_t)(4 * wave) * u_xi + ((size_t)nt * 64 + lane) * 4;
+    // source = wave-uniform 64-bit base + this lane's 32-bit byte offset: the form the SGPR-base addressing mode of
+    // global_load_lds takes (one 32-bit VGPR per request instead of a 64-bit add per lane in front of every request)
+    const char* vsrc = reinterpret_cast<const char*>(p.V + (size_t)(4 * wave) * v_xi + (size_t)mt * 256);
+    const char* usrc = reinterpret_cast<const char*>(p.U + (size_t)(4 * wave) * u_xi + (size_t)nt * 256);
+    const unsigned lane16 = lane * 16;
+    const unsigned lds_ring = (unsigned)(size_t)(wn_lptr)smem;
     // piece k of a stage: k < 4 -> xi = 4 wave + k of V, else xi = 4 wave + k - 4 of U
     auto issue_piece = [&](auto K, int c4, int slot) {
         constexpr int k = decltype(K)::value;
-        char* dst = smem + slot * WN_STAGE + wave * 4096;
-        if constexpr (k < 4) wn_glds16(vsrc + k * v_xi + c4 * v_c4, dst + k * 1024);
-        else wn_glds16(usrc + (k - 4) * u_xi + c4 * u_c4, dst + 16384 + (k - 4) * 1024);
+        const unsigned dst = lds_ring + slot * WN_STAGE + wave * 4096;
+        if constexpr (k < 4) wn_glds16_s(vsrc + (k * v_xi + c4 * v_c4) * 4, lane16, dst + k * 1024);
+        else wn_glds16_s(usrc + ((k - 4) * u_xi + c4 * u_c4) * 4, lane16, dst + 16384 + (k - 4) * 1024);
     };
     auto issue = [&](int c4, int slot) { wn_for<0, WN_DMA>([&](auto K) { issue_piece(K, c4, slot); }); };
 
@@ -649,7 +660,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino8_f32(const WinoArgs p) {
 
 // ------------------------------------------------------------------------------ host side
 static const bool g_wino_off = getenv("YOLO_NO_WINOGRAD") != nullptr;     // A/B switch: the direct kernels
-static const bool g_wino8 = !(getenv("YOLO_WINO_WAVES") && getenv("YOLO_WINO_WAVES")[0] == '4');   // A/B switch: 4 = one wave per SIMD
+static const bool g_wino8 = getenv("YOLO_WINO_WAVES") && getenv("YOLO_WINO_WAVES")[0] == '8';      // A/B switch: 8 = conv_wino8_f32 (measured equal)
 
 size_t wino_weight_elems(int cout, int cin, int ks) {
     if (ks != 3 || cin % 4) return 0;
@@ -679,7 +690,10 @@ bool wino_supported(const yolo_conv_desc* d) {
 // Looks at the layer's shape only, never at the batch size (an image's result may not depend on its neighbours).
 bool wino_eligible(const yolo_conv_desc* d) {
     if (g_wino_off || !wino_supported(d)) return false;
-    return d->cin >= 128 && d->cout >= 64;
+    // measured at batch 32 (tools/conv_bench.py --tile 13 / 7): 64 -> 128 at 104 x 104 387 vs 433-460 us, 128 -> 256 at 52 x 52 353 vs
+    // 425-470, 256 -> 512 at 26 x 26 274 vs 440-515, 512 -> 1024 at 13 x 13 313-323 vs 430; 32 -> 64 at 208 x 208 would be 8 stages per
+    // workgroup behind a 709 MB transform pass: stays direct
+    return d->cin >= 64 && d->cout >= 64;
 }
 
 size_t wino_workspace_bytes(const yolo_conv_desc* d) {
