@@ -227,7 +227,7 @@ int yolo_head_grad_to_nhwc(const float* dp, const int64_t* strides5, void* out, 
 enum { YOLO_FN_FILL_ZERO = 1, YOLO_FN_COPY_D2D, YOLO_FN_NCHW_TO_NHWC, YOLO_FN_STEM_FWD, YOLO_FN_CONV_FWD, YOLO_FN_BN_STATS,
        YOLO_FN_BN_ACT_FWD, YOLO_FN_BN_ACT_BWD, YOLO_FN_UPSAMPLE2X_BWD, YOLO_FN_CONV_WGRAD, YOLO_FN_PACK_WEIGHTS_DGRAD,
        YOLO_FN_PACK_WEIGHTS_BATCH, YOLO_FN_CONV_DGRAD_S2, YOLO_FN_HEAD_GRAD_TO_NHWC, YOLO_FN_CONV_FWD_STATS,
-       YOLO_FN_BN_STATS_FROM_PARTIALS, YOLO_FN_CONV_DGRAD_BSTATS, YOLO_FN_BN_ACT_BWD_ROWS };
+       YOLO_FN_BN_STATS_FROM_PARTIALS, YOLO_FN_CONV_DGRAD_BSTATS, YOLO_FN_BN_ACT_BWD_ROWS, YOLO_FN_CONV_FWD_WS };
 #define YOLO_CALL_MAX_ARGS 24
 typedef struct yolo_call { int32_t fn; int32_t reserved; uint64_t a[YOLO_CALL_MAX_ARGS]; } yolo_call;
 typedef struct yolo_reloc { int32_t call, arg, slot, reserved; int64_t offset; } yolo_reloc;

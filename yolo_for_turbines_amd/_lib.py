@@ -52,7 +52,7 @@ FN_IDS = {name: i + 1 for i, name in enumerate((
     "yolo_fill_zero", "yolo_copy_d2d", "yolo_nchw_to_nhwc", "yolo_stem_fwd", "yolo_conv_fwd", "yolo_bn_stats", "yolo_bn_act_fwd",
     "yolo_bn_act_bwd", "yolo_upsample2x_bwd", "yolo_conv_wgrad", "yolo_pack_weights_dgrad", "yolo_pack_weights_batch",
     "yolo_conv_dgrad_s2", "yolo_head_grad_to_nhwc", "yolo_conv_fwd_stats", "yolo_bn_stats_from_partials",
-    "yolo_conv_dgrad_bstats", "yolo_bn_act_bwd_rows"))}
+    "yolo_conv_dgrad_bstats", "yolo_bn_act_bwd_rows", "yolo_conv_fwd_ws"))}
 
 
 class YoloLibError(RuntimeError):

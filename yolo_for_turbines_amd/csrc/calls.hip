@@ -59,6 +59,10 @@ int run_one(int fn, const uint64_t* a, void* s) {
     case YOLO_FN_CONV_FWD:
         return yolo_conv_fwd(p_of<const yolo_conv_desc>(a[0]), p_of<const void>(a[1]), p_of<const void>(a[2]), p_of<const float>(a[3]),
                              p_of<const float>(a[4]), p_of<const void>(a[5]), p_of<void>(a[6]), p_of<int32_t>(a[7]), s);
+    case YOLO_FN_CONV_FWD_WS:
+        return yolo_conv_fwd_ws(p_of<const yolo_conv_desc>(a[0]), p_of<const void>(a[1]), p_of<const void>(a[2]), p_of<const float>(a[3]),
+                                p_of<const float>(a[4]), p_of<const void>(a[5]), p_of<void>(a[6]), p_of<void>(a[7]), (size_t)a[8],
+                                p_of<int32_t>(a[9]), s);
     case YOLO_FN_BN_STATS:
         return yolo_bn_stats(p_of<const void>(a[0]), (int)a[1], (int)a[2], (int)a[3], (int)a[4], p_of<const float>(a[5]),
                              p_of<const float>(a[6]), f_of(a[7]), f_of(a[8]), p_of<float>(a[9]), p_of<float>(a[10]), p_of<float>(a[11]),

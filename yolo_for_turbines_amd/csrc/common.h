@@ -200,6 +200,7 @@ int conv1_rs_launch(const yolo_conv_desc* d, const void* x, const void* w, const
 // the output transform in the epilogue). U sits behind the fragment-order copy in the packed fp32 buffer.
 size_t wino_weight_elems(int cout, int cin, int ks);
 int wino_pack(const float* w_oihw, float* U, int cout, int cin, hipStream_t s);
+int wino_pack_dgrad(const float* w_oihw, float* U, int cout, int cin, hipStream_t s);
 bool wino_supported(const yolo_conv_desc* d);
 bool wino_eligible(const yolo_conv_desc* d);
 size_t wino_workspace_bytes(const yolo_conv_desc* d);

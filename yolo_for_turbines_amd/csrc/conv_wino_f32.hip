@@ -76,7 +76,10 @@ __device__ __forceinline__ void wn_for(Fn&& fn) {
 
 // ------------------------------------------------------------------------------ weights: U = G g G^T
 // G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
-__global__ void wino_pack_f32(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int coutp, long long total) {
+// dgrad = 1: the input-gradient convolution's filters g'[n = ci][k = co][p][q] = w[co][ci][2 - p][2 - q] (cout = number of rows n = the
+// forward's cin, cin = number of k = the forward's cout rounded up to 32: columns beyond `klim` are zero)
+__global__ void wino_pack_f32(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int coutp, long long total,
+                              int dgrad, int klim) {
     const int C4 = cin / 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 3);
@@ -86,13 +89,15 @@ __global__ void wino_pack_f32(const float* __restrict__ w, float* __restrict__ U
         const int c4 = (int)(r1 % C4);
         const int xi = (int)(r1 / C4);
         float out = 0.f;
-        if (co < cout) {
-            const float* g = w + ((size_t)co * cin + 4 * c4 + e) * 9;
+        const int kk = 4 * c4 + e;
+        if (co < cout && (!dgrad || kk < klim)) {
+            // forward: row co, column kk of w[cout][cin]; dgrad: row co is a forward INPUT channel, column kk a forward output channel
+            const float* g = dgrad ? w + ((size_t)kk * cout + co) * 9 : w + ((size_t)co * cin + kk) * 9;
             const int a = xi >> 2, b = xi & 3;
             double t[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const double g0 = g[q], g1 = g[3 + q], g2 = g[6 + q];
+                const double g0 = dgrad ? g[8 - q] : g[q], g1 = dgrad ? g[5 - q] : g[3 + q], g2 = dgrad ? g[2 - q] : g[6 + q];
                 t[q] = a == 0 ? g0 : a == 1 ? 0.5 * (g0 + g1 + g2) : a == 2 ? 0.5 * (g0 - g1 + g2) : g2;
             }
             const double u = b == 0 ? t[0] : b == 1 ? 0.5 * (t[0] + t[1] + t[2]) : b == 2 ? 0.5 * (t[0] - t[1] + t[2]) : t[2];
@@ -671,8 +676,18 @@ int wino_pack(const float* w_oihw, float* U, int cout, int cin, hipStream_t s) {
     const long long total = (long long)wino_weight_elems(cout, cin, 3);
     if (!total) return fail(YOLO_ERR_ARG, "wino_pack: cin %% 4");
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(wino_pack_f32, dim3(grid), dim3(256), 0, s, w_oihw, U, cout, cin, round_up(cout, 64), total);
+    hipLaunchKernelGGL(wino_pack_f32, dim3(grid), dim3(256), 0, s, w_oihw, U, cout, cin, round_up(cout, 64), total, 0, cin);
     return check_launch("wino_pack_f32");
+}
+
+// filters of the input-gradient convolution (3x3 stride 1): dx = conv(dz, g'), rows = the forward's cin, K = the forward's cout padded to 32
+int wino_pack_dgrad(const float* w_oihw, float* U, int cout, int cin, hipStream_t s) {
+    const int coutp = round_up(cout, 32);
+    const long long total = (long long)wino_weight_elems(cin, coutp, 3);
+    if (!total) return fail(YOLO_ERR_ARG, "wino_pack_dgrad: shape");
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wino_pack_f32, dim3(grid), dim3(256), 0, s, w_oihw, U, cin, coutp, round_up(cin, 64), total, 1, cout);
+    return check_launch("wino_pack_f32(dgrad)");
 }
 
 // what the kernels can run at all (tile 13 forces it on anything that passes)

@@ -212,7 +212,7 @@ size_t yolo_packed_dgrad_bytes(int cout, int cin, int ksize, int flip, int dtype
     const int coutp = round_up(cout, 32);
     if (flip && dtype != YOLO_F32) return h16_frag_elems(cin, coutp, ksize) * 2;
     if (!flip && dtype != YOLO_F32) return (ksize == 3 && cout % 32 == 0) ? h16_dgrad_s2_elems(cout, cin) * 2 : 0;
-    return (v0_packed_elems(cin, coutp, ksize) + v2_frag_elems(cin, coutp, ksize)) * sizeof(float);
+    return (v0_packed_elems(cin, coutp, ksize) + v2_frag_elems(cin, coutp, ksize) + (flip ? wino_weight_elems(cin, coutp, ksize) : 0)) * sizeof(float);
 }
 
 int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int cin, int ksize, int flip, int dtype, void* stream) {
@@ -231,7 +231,10 @@ int yolo_pack_weights_dgrad(const float* w_oihw, void* w_packed, int cout, int c
     const int KT = (coutp / 32) * ksize * ksize;
     grid = (int)((ftotal + 255) / 256 < 8192 ? (ftotal + 255) / 256 : 8192);
     hipLaunchKernelGGL(pack_dgrad_frag, dim3(grid), dim3(256), 0, s, w_oihw, (float*)w_packed + total, cout, cin, ksize, KT, ftotal);
-    return check_launch("pack_dgrad_frag");
+    rc = check_launch("pack_dgrad_frag");
+    // third section, as in yolo_pack_weights: the Winograd-domain filters of the gradient convolution (yolo_conv_fwd_ws)
+    if (rc || !wino_weight_elems(cin, coutp, ksize)) return rc;
+    return wino_pack_dgrad(w_oihw, (float*)w_packed + total + ftotal, cout, cin, s);
 }
 
 /* dx (N,2Ho,2Wo,cin) = transposed 3x3 stride-2 conv of dz (N,Ho,Wo,cout) [+ residual]; w_packed from

@@ -74,7 +74,7 @@ class TrainPlan:
                      bool(L.lib().yolo_stem_supported(op0["block"].conv.in_channels, op0["block"].conv.out_channels, op0["k"], op0["s"])))
         self.z, self.stats = [], []
         self.fused_stats = []             # per op: (rows, ld) of the partial sums its convolution's epilogue writes, or None
-        max_bn, max_wg, max_st = 256, 256, 0
+        max_bn, max_wg, max_st, max_cw = 256, 256, 0, 0
         lib = L.lib()
         for op in prog.ops:
             blk, cv = op["block"], op["block"].conv
@@ -99,11 +99,20 @@ class TrainPlan:
                 self.stats.append(None)
                 max_bn = max(max_bn, lib.yolo_bn_workspace_bytes(m, (cv.out_channels + 31) // 32 * 32))
             self.fused_stats.append(fs)
+            # caller-owned workspace of yolo_conv_fwd_ws (fp32 3x3 stride 1 -> Winograd): the raw forward convolution and the
+            # input-gradient convolution (cin' = cout rounded up to 32, cout' = cin) of this block
+            coutp = (cv.out_channels + 31) // 32 * 32
+            for dd in (_desc(self.B, op["x"], cv.in_channels, cv.out_channels, op["k"], op["s"], cv.out_channels, 0, dtype=self.code),
+                       _desc(self.B, TView(-1, coutp, op["Ho"], op["Wo"], coutp, 0), coutp, cv.in_channels, op["k"], 1,
+                             op["x"].ld, op["x"].off, dtype=self.code)):
+                if op["s"] == 1:
+                    max_cw = max(max_cw, lib.yolo_conv_workspace_bytes(dd))
             max_wg = max(max_wg, lib.yolo_wgrad_workspace_bytes(self.B, op["x"].H, op["x"].W, cv.in_channels, cv.out_channels,
                                                                  op["k"], op["s"], self.code))
         self.bn_ws = torch.empty(max_bn, dtype=torch.uint8, device=device)
         self.st_ws = torch.empty(max(max_st, 16), dtype=torch.uint8, device=device)
         self.wg_ws = torch.empty(max_wg, dtype=torch.uint8, device=device)
+        self.conv_ws = torch.empty(max(max_cw, 16), dtype=torch.uint8, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.blocks = [op["block"] for op in prog.ops]
         self.fwd_tape = None              # tape.CallTape of the train-mode forward
@@ -194,8 +203,8 @@ def _forward_launches(lib, state, plan: TrainPlan, x, xin, preds, stream):
                                             stream), "yolo_conv_fwd_stats")
         else:
             d = _desc(B, xv, cv.in_channels, cout, op["k"], op["s"], cout, 0, dtype=code)
-            L.check(lib.yolo_conv_fwd(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
-                                      plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd(raw)")
+            L.check(lib.yolo_conv_fwd_ws(d, plan.view_ptr(xv), pk.w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 0, z.data_ptr(),
+                                         plan.conv_ws.data_ptr(), plan.conv_ws.numel(), plan.nan_flag.data_ptr(), stream), "yolo_conv_fwd_ws(raw)")
         bn = blk.batch_norm
         st = plan.stats[i]
         m = B * op["Ho"] * op["Wo"]
@@ -550,8 +559,8 @@ def _backward(state, model, plan: TrainPlan, dpreds, need, seeds=None, want_inpu
                             "yolo_conv_dgrad_bstats")
                     pending[P] = (bst, rows, rld_, optr, old, ooff)
                 else:
-                    L.check(lib.yolo_conv_fwd(d, dz.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), rptr, optr, 0, stream),
-                            "dgrad (stride 1)")
+                    L.check(lib.yolo_conv_fwd_ws(d, dz.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), rptr, optr,
+                                                 plan.conv_ws.data_ptr(), plan.conv_ws.numel(), 0, stream), "dgrad (stride 1)")
             else:
                 L.check(lib.yolo_conv_dgrad_s2(dz.data_ptr(), dz_ld, 0, wp.data_ptr(), rptr, rld, roff, optr, old, ooff, B, Ho, Wo,
                                                cin, cout, code, stream), "yolo_conv_dgrad_s2")
