@@ -450,222 +450,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
 #endif
 }
 
-// ------------------------------------------------------------------------------ the same launch with TWO waves per SIMD
-// conv_wino_f32 above keeps all 16 xi of a (tile, channel) in one lane: 256 accumulator registers, ONE wave per SIMD - and that
-// wave issues everything: per stage 32 MFMAs, 32 fragment reads and 8 LDS-DMA requests, each of which holds the wave for 60-185
-// cycles with one MFMA in flight behind it. Stamps (tools/wino_stamps.py): 2,545 cycles per stage for 2,048 of matrix work
-// wherever the requests are placed; 2,052 with requests, barrier and reads ablated. Here a workgroup is 512 threads: waves
-// 0-3 take xi 0..7 (rows 0, 1 of the 4 x 4 product matrix M), waves 4-7 xi 8..15 (rows 2, 3) of the same 64 tiles x 64
-// channels; 128 accumulator registers per wave, two waves per SIMD: while one sits in a request, a wait or the barrier, the
-// other one's MFMAs keep the matrix pipe busy. The output transform Y = A^T M A is linear in the rows of M: each half
-// transforms ITS two rows into a partial 2 x 2 output tile, both partials go through LDS (the staging the stores need
-// anyway) and are added by the threads that store. Everything else as above.
-constexpr int W8_DMA = 4;                // DMA wave-instructions per wave and stage
-
-template <int ACT, bool RES>
-__global__ __launch_bounds__(512, 1) void conv_wino8_f32(const WinoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, m = lane & 31;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int nt = q % p.n_nt, mt = (q / p.n_nt) * 8 + xcd;
-    if (mt >= p.n_mt) return;
-    const int g = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 1;
-#ifdef WN_STAMPS
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
-
-    // ---- DMA roles: this wave moves xi = 2 wave, 2 wave + 1 of V and of U, lane = row
-    const size_t v_xi = (size_t)p.C4 * p.Tpad * 4, v_c4 = (size_t)p.Tpad * 4;
-    const size_t u_xi = (size_t)p.C4 * p.CoutPad * 4, u_c4 = (size_t)p.CoutPad * 4;
-    const float* vsrc = p.V + (size_t)(2 * wave) * v_xi + ((size_t)mt * 64 + lane) * 4;
-    const float* usrc = p.U + (size_t)(2 * wave) * u_xi + ((size_t)nt * 64 + lane) * 4;
-    auto issue_piece = [&](auto K, int c4, int slot) {
-        constexpr int k = decltype(K)::value;
-        char* dst = smem + slot * WN_STAGE + wave * 2048;
-        if constexpr (k < 2) wn_glds16(vsrc + k * v_xi + c4 * v_c4, dst + k * 1024);
-        else wn_glds16(usrc + (k - 2) * u_xi + c4 * u_c4, dst + 16384 + (k - 2) * 1024);
-    };
-    auto issue = [&](int c4, int slot) { wn_for<0, W8_DMA>([&](auto K) { issue_piece(K, c4, slot); }); };
-
-    // ---- fragment addresses: xi = 8 g + l; row 32 wm + m of V (B operand), row 32 wn + m of U (A operand), channels 2h, 2h + 1
-    const unsigned lds0 = (unsigned)(size_t)(wn_lptr)smem;
-    const unsigned vb = lds0 + g * 8192 + (32 * wm + m) * 16 + h * 8;
-    const unsigned ub = lds0 + 16384 + g * 8192 + (32 * wn + m) * 16 + h * 8;
-
-    // scale / shift of the channels this thread STORES (4 (tid % 16) .. + 3 of the block): requested before the ring's first pieces
-    const int c16 = tid & 15;
-    const int co_t = nt * 64 + 4 * c16;
-    const bool cv = co_t < p.Cout;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + (cv ? co_t : 0));
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + (cv ? co_t : 0));
-
-    f32x2 fa[8], fb[8];
-    const int nst = p.C4;
-    issue(0, 0);
-    if (nst > 1) issue(1, 1);
-    if (nst > 2) issue(2, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-#pragma unroll
-    for (int x = 0; x < 8; ++x) asm volatile("" : "+a"(acc[x]));
-    __builtin_amdgcn_sched_barrier(0);
-    if (nst > 2) wn_wait_vmcnt<2 * W8_DMA>();
-    else if (nst > 1) wn_wait_vmcnt<W8_DMA>();
-    else wn_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef WN_STAMPS
-    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    wn_read2<0>(fa[0], fb[0], ub, vb);
-    wn_read2<1024>(fa[1], fb[1], ub, vb);
-
-    int slot = 0;
-    for (int st = 0; st < nst; ++st) {
-        const unsigned sb = (unsigned)slot * WN_STAGE;
-        const int ns = (slot + 1) & (WN_SLOTS - 1);
-        const unsigned nb = (unsigned)ns * WN_STAGE;
-        wn_for<0, 8>([&](auto X) {
-            constexpr int x = decltype(X)::value;
-            if constexpr (x == 6) {
-                // stage st + 1 has to be in LDS for everybody before its first fragments are read; the slot of stage st - 1
-                // (= of stage st + 3) is free once everybody is here
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 2 < nst) wn_wait_vmcnt<W8_DMA>();
-                else wn_wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (x + 2 < 8) wn_read2<(x + 2) * 1024>(fa[x + 2], fb[x + 2], ub + sb, vb + sb);
-            // reads issued after those of xi = x and still in flight: x < 6 -> x + 1, x + 2; 6 -> 7; 7 -> the next stage's 0
-            constexpr int after = x < 6 ? 4 : 2;
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
-            if constexpr (x >= 6) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 3 < nst) issue_piece(std::integral_constant<int, 2 * (x - 6)>{}, st + 3, (slot + 3) & (WN_SLOTS - 1));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][1], fb[x][1], acc[x], 0, 0, 0);
-            if constexpr (x >= 6) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 3 < nst) issue_piece(std::integral_constant<int, 2 * (x - 6) + 1>{}, st + 3, (slot + 3) & (WN_SLOTS - 1));
-                wn_read2<(x - 6) * 1024>(fa[x - 6], fb[x - 6], ub + nb, vb + nb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        slot = ns;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the stage after the last
-#ifdef WN_STAMPS
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
-#endif
-
-    // ------------------------------------------------------------------ partial output transform, staging, epilogue
-    // A^T = [1 1 1 0; 0 1 -1 -1]: rows 0, 1 of M give t0 = M0 + M1, t1 = M1; rows 2, 3 give t0 = M2, t1 = -M2 - M3
-    constexpr int OLD = 68;
-    constexpr int HALF = 256 * OLD * 4;                                // bytes of one half's staging: [4 pixels][64 tiles][64 + 4]
-    float* ost = reinterpret_cast<float*>(smem + g * HALF);
-    int* tab = reinterpret_cast<int*>(smem + 2 * HALF);
-    f32x4 scv = sc, shv = sh;
-    asm volatile("" : "+v"(scv), "+v"(shv));                           // the compiler's wait for them goes HERE: nothing is in flight
-    __syncthreads();                                                    // every wave is done with the ring (no DMA is in flight)
-    if (tid < 64) {
-        const int t = mt * 64 + tid;
-        const bool tv = t < p.T;
-        const int tt = tv ? t : 0;
-        const int per = p.th * p.tw;
-        const int n = tt / per, rem = tt - n * per;
-        const int ty = rem / p.tw, tx = rem - ty * p.tw;
-        tab[tid] = (n * p.H + 2 * ty) * p.W + 2 * tx;
-        tab[64 + tid] = (tv ? 1 : 0) | (2 * tx + 1 < p.W ? 2 : 0) | (2 * ty + 1 < p.H ? 4 : 0);
-    }
-    {
-        float* dst = ost + (32 * wm + m) * OLD + 32 * wn + 4 * h;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            f32x4 o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * gq + e;
-                float t0[4], t1[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (g == 0) { t0[b] = acc[b][r] + acc[4 + b][r]; t1[b] = acc[4 + b][r]; }
-                    else { t0[b] = acc[b][r]; t1[b] = -acc[b][r] - acc[4 + b][r]; }
-                }
-                o[0][e] = t0[0] + t0[1] + t0[2];
-                o[1][e] = t0[1] - t0[2] - t0[3];
-                o[2][e] = t1[0] + t1[1] + t1[2];
-                o[3][e] = t1[1] - t1[2] - t1[3];
-            }
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) *reinterpret_cast<f32x4*>(dst + pp * 64 * OLD + 8 * gq) = o[pp];
-        }
-    }
-    __syncthreads();
-    // this thread's 8 rows of the staged tile: pixel pp = it / 2 of tile (tid / 16) + 32 (it % 2), channels 4 (tid % 16) ..
-    int pix[8];
-    bool pv[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int tl = (tid >> 4) + 32 * (it & 1), pp = it >> 1;
-        const int fl = tab[64 + tl];
-        pv[it] = cv && (fl & 1) && (!(pp & 1) || (fl & 2)) && (!(pp & 2) || (fl & 4));
-        pix[it] = pv[it] ? tab[tl] + (pp & 1) + (pp >> 1) * p.W : 0;
-    }
-    f32x4 rr[8];
-    if (RES) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            rr[it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix[it] * p.r_ld + p.r_off + (cv ? co_t : 0));
-    }
-    bool saw_nan = false;
-    f32x4 va[8], vb2[8];
-    const float* s0 = reinterpret_cast<const float*>(smem) + (tid >> 4) * OLD + 4 * c16;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        va[it] = *reinterpret_cast<const f32x4*>(s0 + 32 * it * OLD);
-        vb2[it] = *reinterpret_cast<const f32x4*>(s0 + 32 * it * OLD + HALF / 4);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>((va[it][e] + vb2[it][e]) * scv[e] + shv[e]);
-        if (RES) v += rr[it];
-        if (pv[it]) {
-            saw_nan |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
-            *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = v;
-        }
-    }
-#ifdef WN_STAMPS
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.nan_flag) + (size_t)blockIdx.x * 6;
-        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = hwid; d[5] = xcc;
-    }
-    (void)saw_nan;
-#else
-    if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
-#endif
-}
-
 // ------------------------------------------------------------------------------ host side
 static const bool g_wino_off = getenv("YOLO_NO_WINOGRAD") != nullptr;     // A/B switch: the direct kernels
-static const bool g_wino8 = getenv("YOLO_WINO_WAVES") && getenv("YOLO_WINO_WAVES")[0] == '8';      // A/B switch: 8 = conv_wino8_f32 (measured equal)
 
 size_t wino_weight_elems(int cout, int cin, int ks) {
     if (ks != 3 || cin % 4) return 0;
@@ -740,17 +526,6 @@ int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, con
     a.n_mt = Tpad / 64; a.n_nt = a.CoutPad / 64;
     const int grid = 8 * a.n_nt * ceil_div(a.n_mt, 8);
     const bool res = d->flags & YOLO_FLAG_RESIDUAL;
-    if (d->tile == 14 || (d->tile != 13 && d->tile < 16 && g_wino8)) {       // two waves per SIMD (conv_wino8_f32)
-        const size_t lds8 = (size_t)2 * 256 * 68 * 4 + 512;                    // the two staged partial tiles (> the 128 KiB ring)
-        auto go8 = [&](auto kern) -> int {
-            static LdsOnce once;
-            if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), lds8, "conv_wino8_f32")) return rc;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds8, s, a);
-            return check_launch("conv_wino8_f32");
-        };
-        YOLO_SWITCH_ACT(d->act, return res ? go8(&conv_wino8_f32<ACT, true>) : go8(&conv_wino8_f32<ACT, false>));
-        return fail(YOLO_ERR_ARG, "conv winograd: activation");
-    }
     const size_t lds = (size_t)WN_SLOTS * WN_STAGE;
     auto go = [&](auto kern) -> int {
         static LdsOnce once;
