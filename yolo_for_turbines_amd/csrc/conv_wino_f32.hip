@@ -196,10 +196,13 @@ constexpr int WN_AHEAD = 4;              // fragment reads kept in flight, in xi
 #endif
 constexpr int WN_BAR = 16 - WN_AHEAD;    // the stage's barrier sits in front of this xi (all reads of the stage are issued by then)
 
-// PROBE (diagnostic build only, garbage results): 1 = no stage barrier / DMA wait, 2 = no DMA requests in the loop, 4 = no fragment reads
+// PROBE (diagnostic build only, garbage results): 1 = no stage barrier / DMA wait, 2 = no DMA requests in the loop, 4 = no fragment reads;
+// 8 + e ablates a part of the EPILOGUE instead: e = 0 the stores, 1 the residual requests, 3 staging and stores
 template <int ACT, bool RES, int PROBE = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MP = (PROBE & 8) ? 0 : PROBE;          // main-loop ablations
+    constexpr int EP = (PROBE & 8) ? (PROBE & 3) : -1;   // epilogue ablation
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, m = lane & 31;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
         //   2: as 1, between the two MFMAs of the xi;  3: one behind each of the eight MFMAs after the barrier
         auto dma_at = [&](auto XX, auto HH) {
             constexpr int x = decltype(XX)::value, half = decltype(HH)::value;
-            if constexpr (PROBE & 2) return;
+            if constexpr (MP & 2) return;
             if constexpr (WN_DMA_MODE == 0) {
                 if constexpr (x == WN_BAR && half == 1) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -316,18 +319,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
                 // stage st + 1 has to be in LDS for everybody before its first fragments are read; the slot of stage st - 1
                 // (= of stage st + 3) is free once everybody is here
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(PROBE & 1)) {
+                if constexpr (!(MP & 1)) {
                     if (st + 2 < nst) wn_wait_vmcnt<WN_DMA>();
                     else wn_wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (x + WN_AHEAD < 16 && !(PROBE & 4)) wn_read2<(x + WN_AHEAD) * 1024>(fa[x + WN_AHEAD], fb[x + WN_AHEAD], ub + sb, vb + sb);
+            if constexpr (x + WN_AHEAD < 16 && !(MP & 4)) wn_read2<(x + WN_AHEAD) * 1024>(fa[x + WN_AHEAD], fb[x + WN_AHEAD], ub + sb, vb + sb);
             // reads issued after those of xi = x and still in flight (LDS operations return in order): 2 per xi. Behind the
             // barrier: xi 12 -> 13, 14, 15; 13 -> 14, 15; 14 -> 15 and the next stage's 0, 1; 15 -> the next stage's 0 .. 3
             constexpr int after = x < WN_BAR ? 2 * WN_AHEAD : x == 12 ? 6 : x == 13 ? 4 : x == 14 ? 6 : 8;
-            if constexpr (!(PROBE & 4)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
+            if constexpr (!(MP & 4)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
             else asm volatile("" : "+v"(fa[x]), "+v"(fb[x]));
             acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
             dma_at(X, std::integral_constant<int, 0>{});
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
             if constexpr (x == WN_BAR + 1 || x == WN_BAR + 2) {
                 constexpr int y = 2 * (x - WN_BAR - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(PROBE & 4)) {
+                if constexpr (!(MP & 4)) {
                     wn_read2<y * 1024>(fa[y], fb[y], ub + nb, vb + nb);
                     wn_read2<(y + 1) * 1024>(fa[y + 1], fb[y + 1], ub + nb, vb + nb);
                 }
@@ -387,10 +390,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
         pix[it] = pv[it] ? tab[tl] + (pp & 1) + (pp >> 1) * p.W : 0;
     }
     f32x4 rr[16];
-    if (RES) {
+    if (RES && EP != 1) {
 #pragma unroll
         for (int it = 0; it < 16; ++it)
             rr[it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix[it] * p.r_ld + p.r_off + (cv ? co_t : 0));
+    } else if (RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) rr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_sched_barrier(0);                                // all residual rows are requested before the transform starts
     {
@@ -417,7 +423,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
                 }
             }
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) *reinterpret_cast<f32x4*>(dst + pp * 64 * OLD + 8 * g) = o[pp];
+            for (int pp = 0; pp < 4; ++pp) {
+                if constexpr (EP == 3) { asm volatile("" :: "v"(o[pp])); continue; }
+                *reinterpret_cast<f32x4*>(dst + pp * 64 * OLD + 8 * g) = o[pp];
+            }
         }
     }
     __syncthreads();
@@ -431,7 +440,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
         if (RES) v += rr[it];
         if (pv[it]) {
             saw_nan |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
-            *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = v;
+            if constexpr (EP == 0 || EP == 3) asm volatile("" :: "v"(v));
+            else *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = v;
         }
     }
 #ifdef WN_STAMPS
@@ -540,6 +550,9 @@ int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, con
     case 3: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 3>);
     case 4: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 4>);
     case 7: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 7>);
+    case 8: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 8>);
+    case 9: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 9>);
+    case 11: return go(&conv_wino_f32<YOLO_ACT_LEAKY, true, 11>);
     default: break;
     }
 #endif
