@@ -1750,7 +1750,7 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_fp32_winograd_kernel(yt, case):
-    """conv_wino_f32 through the C-ABI (`yolo_conv_fwd_ws`, tile = 13): ragged tile / channel blocks, odd and non-square maps,
+    """conv_wino_f32 / conv_wino2_f32 through the C-ABI (`yolo_conv_fwd_ws`, tile = 13 / 14): ragged tile / channel blocks, odd and non-square maps,
     1-3 stage rings, ld / off views, residual, every activation; the rest of the output buffer untouched; NaN flag. Reference:
     fp64 convolution of the same operands (model.py:80-86, 115-121) - the bar is what Winograd's transforms cost in fp32
     (1e-5 of max|y|; the north-star bar is 1e-3). The direct kernel (tile 0 without a workspace) is checked beside it."""
@@ -1785,7 +1785,7 @@ def test_fp32_winograd_kernel(yt, case):
     assert need == (tiles + 63) // 64 * 64 * cin * 64
     ws = torch.full((need + 64,), 0x7f, dtype=torch.uint8, device=dev)          # NaN-ish garbage: the transform pass must define all it reads
     errs = {}
-    for tile, wsp, wsb in ((13, ws.data_ptr(), need), (0, 0, 0)):    # Winograd; the direct kernel
+    for tile, wsp, wsb in ((13, ws.data_ptr(), need), (14, ws.data_ptr(), need), (0, 0, 0)):    # Winograd in one / two passes; the direct kernel
         yd = y0.clone().to(dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(lib.yolo_conv_fwd_ws(desc(tile), xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), shd.data_ptr(), rd.data_ptr() if residual else 0,
@@ -1797,7 +1797,7 @@ def test_fp32_winograd_kernel(yt, case):
         keep = torch.ones(y_ld, dtype=torch.bool)
         keep[y_off:y_off + cout] = False
         assert torch.equal(got[..., keep], y0[..., keep])           # neighbouring channels of the buffer untouched
-    assert errs[13] <= 1e-5 and errs[0] <= 5e-6, errs
+    assert errs[13] <= 1e-5 and errs[14] <= 1e-5 and errs[0] <= 5e-6, errs
     assert int(ws[need:].min()) == 0x7f                              # nothing written past the stated size
     # too small a workspace: tile 13 refuses, tile 0 silently takes the direct kernel
     yd = y0.clone().to(dev)

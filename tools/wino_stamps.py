@@ -12,7 +12,7 @@ from tools.conv_bench import LAYERS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c52_3x3"
 residual = len(sys.argv) > 2 and sys.argv[2] == "res"
-tile = int(sys.argv[3]) if len(sys.argv) > 3 else 13          # 16 + bits: timing probes (1 no barrier, 2 no DMA, 4 no fragment reads)
+tile = int(sys.argv[3]) if len(sys.argv) > 3 else 13          # 14: two passes, two workgroups per CU; 16 + bits: timing probes (1 no barrier, 2 no DMA, 4 no fragment reads)
 H, cin, cout, k, s = LAYERS[name]
 B = 32
 lib = L.lib()

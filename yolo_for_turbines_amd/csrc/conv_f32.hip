@@ -355,7 +355,7 @@ static int conv_fwd_impl(const yolo_conv_desc* d, const void* x, const void* w, 
     if (d->tile == kTileRs) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 12 needs a 1x1 with 256 / 384 / 512 input channels and cout %% 128 == 0");
     // 3x3 stride 1 by Winograd F(2x2, 3x3): tile 13 explicitly, or the heuristic when the caller brought a large enough workspace
     // (yolo_conv_fwd itself has none: the library allocates nothing)
-    if (d->tile == kTileWino || (d->tile >= 16 && d->ksize == 3 && wino_supported(d)) ||      // 16+: timing probes of the diagnostic library (make wstamps)
+    if (d->tile == kTileWino || d->tile == kTileWino + 1 || (d->tile >= 16 && d->ksize == 3 && wino_supported(d)) ||      // 16+: timing probes of the diagnostic library (make wstamps)
         (d->tile == 0 && wino_eligible(d) && ws && ws_bytes >= wino_workspace_bytes(d))) {
         if (!wino_supported(d)) return fail(YOLO_ERR_UNSUPPORTED, "conv: tile 13 needs fp32 3x3 stride 1 with NHWC output and channel counts %% 4 == 0");
         const float* U = (const float*)w + v0_packed_elems(d->cout, d->cin, d->ksize) + v2_frag_elems(d->cout, d->cin, d->ksize);
@@ -395,7 +395,7 @@ int yolo_conv_fwd(const yolo_conv_desc* d, const void* x, const void* w_packed, 
 
 size_t yolo_conv_workspace_bytes(const yolo_conv_desc* d) {
     if (yolo::validate(d)) return 0;
-    if (d->tile == yolo::kTileWino || d->tile >= 16 || (d->tile == 0 && yolo::wino_eligible(d))) return yolo::wino_workspace_bytes(d);
+    if (d->tile == yolo::kTileWino || d->tile == yolo::kTileWino + 1 || d->tile >= 16 || (d->tile == 0 && yolo::wino_eligible(d))) return yolo::wino_workspace_bytes(d);
     return 0;
 }
 

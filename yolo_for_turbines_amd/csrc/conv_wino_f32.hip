@@ -460,8 +460,242 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32(const WinoArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------ the same launch in TWO PASSES over xi, two workgroups per CU
+// conv_wino_f32 above needs all 512 registers of a SIMD for ONE wave, and that wave does everything of a tile in turn:
+// 17 k cycles per tile outside the main loop (first-stage latency, zeroing 256 accumulators, the ~1,400 vector instructions of
+// the output transform, residual requests, stores) with the matrix pipe idle - 17 % of a tile at 52 x 52, 30 % at 104 x 104.
+// Here a workgroup walks the K loop twice: pass 0 accumulates xi 0..7 (rows 0, 1 of the 4 x 4 product matrix M) into 128
+// accumulator registers, transforms them into a PARTIAL 2 x 2 output tile (Y = A^T M A is linear in the rows of M) that stays in
+// 64 vector registers, pass 1 does the same for xi 8..15 and adds. 128 + ~110 registers per wave: TWO workgroups per CU, each
+// with its own tile, ring (4 x 16 KiB) and phase - while one is in its prologue, transform or epilogue the other one's MFMAs
+// have the matrix pipe. Same operand bytes per MFMA, same arithmetic up to the order of the transform's additions.
+constexpr int W2_STAGE = 16384;          // bytes per ring stage: V [8][64][4] floats, then U [8][64][4]
+constexpr int W2_DMA = 4;                // DMA wave-instructions per wave and stage
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_wino2_f32(const WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt = q % p.n_nt, mt = (q / p.n_nt) * 8 + xcd;
+    if (mt >= p.n_mt) return;
+    const int wm = wave & 1, wn = wave >> 1;
+#ifdef WN_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st1 = 0;
+#endif
+
+    // ---- DMA roles: this wave moves xi = 8 pass + 2 wave, + 1 of V and of U, lane = row
+    const size_t v_xi = (size_t)p.C4 * p.Tpad * 4, v_c4 = (size_t)p.Tpad * 4;
+    const size_t u_xi = (size_t)p.C4 * p.CoutPad * 4, u_c4 = (size_t)p.CoutPad * 4;
+    const char* v_wave = reinterpret_cast<const char*>(p.V + (size_t)(2 * wave) * v_xi + (size_t)mt * 256);
+    const char* u_wave = reinterpret_cast<const char*>(p.U + (size_t)(2 * wave) * u_xi + (size_t)nt * 256);
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(wn_lptr)smem;
+    auto issue_piece = [&](auto K, int pass, int c4, int slot) {
+        constexpr int k = decltype(K)::value;
+        const unsigned dst = lds0 + slot * W2_STAGE + wave * 2048;
+        if constexpr (k < 2) wn_glds16_s(v_wave + ((size_t)(8 * pass + k) * v_xi + c4 * v_c4) * 4, lane16, dst + k * 1024);
+        else wn_glds16_s(u_wave + ((size_t)(8 * pass + k - 2) * u_xi + c4 * u_c4) * 4, lane16, dst + 8192 + (k - 2) * 1024);
+    };
+    auto issue = [&](int pass, int c4, int slot) { wn_for<0, W2_DMA>([&](auto K) { issue_piece(K, pass, c4, slot); }); };
+
+    // ---- fragment addresses: local xi l; row 32 wm + m of V (B operand), row 32 wn + m of U (A operand), channels 2h, 2h + 1
+    const unsigned vb = lds0 + (32 * wm + m) * 16 + h * 8;
+    const unsigned ub = lds0 + 8192 + (32 * wn + m) * 16 + h * 8;
+
+    // scale / shift of the 4 channels this thread STORES (4 (tid % 16) .. of the block): requested before the ring's first pieces
+    const int c16 = tid & 15;
+    const int co_t = nt * 64 + 4 * c16;
+    const bool cv = co_t < p.Cout;
+    const f32x4 sc_t = *reinterpret_cast<const f32x4*>(p.scale + (cv ? co_t : 0));
+    const f32x4 sh_t = *reinterpret_cast<const f32x4*>(p.shift + (cv ? co_t : 0));
+    const int nst = p.C4;
+    f32x4 py[4][4];                       // the (partial) output tile: [channel run g][pixel] of this lane's tile; pass 1 adds to pass 0's
+    auto run_pass = [&](auto PASS) {
+        constexpr int pass = decltype(PASS)::value;
+        f32x2 fa[8], fb[8];
+        issue(pass, 0, 0);
+        if (nst > 1) issue(pass, 1, 1);
+        if (nst > 2) issue(pass, 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) asm volatile("" : "+a"(acc[x]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (nst > 2) wn_wait_vmcnt<2 * W2_DMA>();
+        else if (nst > 1) wn_wait_vmcnt<W2_DMA>();
+        else wn_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef WN_STAMPS
+        if constexpr (pass == 0) st1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        wn_read2<0>(fa[0], fb[0], ub, vb);
+        wn_read2<1024>(fa[1], fb[1], ub, vb);
+
+        int slot = 0;
+        for (int st = 0; st < nst; ++st) {
+            const unsigned sb = (unsigned)slot * W2_STAGE;
+            const int ns = (slot + 1) & (WN_SLOTS - 1);
+            const unsigned nb = (unsigned)ns * W2_STAGE;
+            wn_for<0, 8>([&](auto X) {
+                constexpr int x = decltype(X)::value;
+                if constexpr (x == 6) {
+                    // stage st + 1 has to be in LDS for everybody before its first fragments are read; the slot of stage st - 1
+                    // (= of stage st + 3) is free once everybody is here
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 2 < nst) wn_wait_vmcnt<W2_DMA>();
+                    else wn_wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (x + 2 < 8) wn_read2<(x + 2) * 1024>(fa[x + 2], fb[x + 2], ub + sb, vb + sb);
+                // reads issued after those of xi = x and still in flight: x < 6 -> x + 1, x + 2; 6 -> 7; 7 -> the next stage's 0
+                constexpr int after = x < 6 ? 4 : 2;
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[x]), "+v"(fb[x]) : "n"(after));
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][0], fb[x][0], acc[x], 0, 0, 0);
+                if constexpr (x >= 6) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 3 < nst) issue_piece(std::integral_constant<int, 2 * (x - 6)>{}, pass, st + 3, (slot + 3) & (WN_SLOTS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][1], fb[x][1], acc[x], 0, 0, 0);
+                if constexpr (x >= 6) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 3 < nst) issue_piece(std::integral_constant<int, 2 * (x - 6) + 1>{}, pass, st + 3, (slot + 3) & (WN_SLOTS - 1));
+                    wn_read2<(x - 6) * 1024>(fa[x - 6], fb[x - 6], ub + nb, vb + nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            slot = ns;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the look-ahead reads of the stage after the last
+        // partial output transform. A^T = [1 1 1 0; 0 1 -1 -1]: rows 0, 1 of M give t0 = M0 + M1, t1 = M1; rows 2, 3 t0 = M2, t1 = -M2 - M3
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * gq + e;
+                float t0[4], t1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if constexpr (pass == 0) { t0[b] = acc[b][r] + acc[4 + b][r]; t1[b] = acc[4 + b][r]; }
+                    else { t0[b] = acc[b][r]; t1[b] = -acc[b][r] - acc[4 + b][r]; }
+                }
+                const float y0 = t0[0] + t0[1] + t0[2], y1 = t0[1] - t0[2] - t0[3];
+                const float y2 = t1[0] + t1[1] + t1[2], y3 = t1[1] - t1[2] - t1[3];
+                if constexpr (pass == 0) {
+                    py[gq][0][e] = y0; py[gq][1][e] = y1; py[gq][2][e] = y2; py[gq][3][e] = y3;
+                } else {
+                    py[gq][0][e] += y0; py[gq][1][e] += y1; py[gq][2][e] += y2; py[gq][3][e] += y3;
+                }
+            }
+        }
+        __syncthreads();                                     // everybody is done with the ring: pass 1's first stages / the staging may overwrite it
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    run_pass(std::integral_constant<int, 1>{});
+#ifdef WN_STAMPS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ------------------------------------------------------------------ epilogue through LDS
+    // The RAW output tile is staged ([pixel of the tile][tile][64 + 4] over the idle ring); the threads that store (16 lanes per
+    // pixel row, 4 channels each - the same 4 for all of a thread's 16 rows) apply the folded BatchNorm, the activation and the
+    // residual: their scale / shift are 8 registers requested at kernel start, all 16 residual rows are requested before the
+    // first staged row is read back.
+    constexpr int OLD = 68;
+    float* ost = reinterpret_cast<float*>(smem);
+    int* tab = reinterpret_cast<int*>(smem + 256 * OLD * 4);        // [64] first output pixel of the tile, [64] flags
+    if (tid < 64) {
+        const int t = mt * 64 + tid;
+        const bool tv = t < p.T;
+        const int tt = tv ? t : 0;
+        const int per = p.th * p.tw;
+        const int n = tt / per, rem = tt - n * per;
+        const int ty = rem / p.tw, tx = rem - ty * p.tw;
+        tab[tid] = (n * p.H + 2 * ty) * p.W + 2 * tx;
+        tab[64 + tid] = (tv ? 1 : 0) | (2 * tx + 1 < p.W ? 2 : 0) | (2 * ty + 1 < p.H ? 4 : 0);
+    }
+    {
+        float* dst = ost + (32 * wm + m) * OLD + 32 * wn + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) *reinterpret_cast<f32x4*>(dst + pp * 64 * OLD + 8 * gq) = py[gq][pp];
+    }
+    __syncthreads();
+    // this thread's 16 rows of the staged tile: pixel pp = it / 4 of tile (tid / 16) + 16 (it % 4), channels 4 (tid % 16) ..
+    bool saw_nan = false;
+    int pix[16];
+    bool pv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int tl = (tid >> 4) + 16 * (it & 3), pp = it >> 2;
+        const int fl = tab[64 + tl];
+        pv[it] = cv && (fl & 1) && (!(pp & 1) || (fl & 2)) && (!(pp & 2) || (fl & 4));
+        pix[it] = pv[it] ? tab[tl] + (pp & 1) + (pp >> 1) * p.W : 0;
+    }
+    f32x4 rr[16];
+    if (RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            rr[it] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix[it] * p.r_ld + p.r_off + (cv ? co_t : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 va[8];
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) va[i8] = *reinterpret_cast<const f32x4*>(ost + ((tid >> 4) + 16 * (8 * half + i8)) * OLD + 4 * c16);
+        // all eight values first (one run of counted waits for the residual rows), then the eight predicated stores: inside a
+        // predicated block the compiler waits for EVERYTHING in flight, i.e. for the previous store's completion
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+            const int it = 8 * half + i8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va[i8][e] = act_c<ACT>(va[i8][e] * sc_t[e] + sh_t[e]);
+            if (RES) va[i8] += rr[it];
+            saw_nan |= pv[it] & ((va[i8][0] != va[i8][0]) | (va[i8][1] != va[i8][1]) | (va[i8][2] != va[i8][2]) | (va[i8][3] != va[i8][3]));
+        }
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) asm volatile("" : "+v"(va[i8]));
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+            const int it = 8 * half + i8;
+            if (pv[it]) *reinterpret_cast<f32x4*>(p.y + (size_t)pix[it] * p.y_ld + p.y_off + co_t) = va[i8];
+        }
+    }
+#ifdef WN_STAMPS
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.nan_flag) + (size_t)blockIdx.x * 6;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = hwid; d[5] = xcc;
+    }
+    (void)saw_nan;
+#else
+    if ((p.flags & YOLO_FLAG_NANCHECK) && saw_nan) atomicOr(p.nan_flag, 2);
+#endif
+}
+
 // ------------------------------------------------------------------------------ host side
 static const bool g_wino_off = getenv("YOLO_NO_WINOGRAD") != nullptr;     // A/B switch: the direct kernels
+// conv_wino2_f32 (two passes, two workgroups per CU) for feature maps of at most this many pixels (shape rule, never the batch):
+// measured 292-297 vs 315-321 us at 13 x 13, equal at 26 x 26 / 52 x 52, 442 vs 372 us at 104 x 104. YOLO_WINO2_MAXPIX=0 switches it off.
+static const long long g_wino2_maxpix = getenv("YOLO_WINO2_MAXPIX") ? atoll(getenv("YOLO_WINO2_MAXPIX")) : 256;
 
 size_t wino_weight_elems(int cout, int cin, int ks) {
     if (ks != 3 || cin % 4) return 0;
@@ -536,6 +770,17 @@ int conv_wino_launch(const yolo_conv_desc* d, const void* x, const float* U, con
     a.n_mt = Tpad / 64; a.n_nt = a.CoutPad / 64;
     const int grid = 8 * a.n_nt * ceil_div(a.n_mt, 8);
     const bool res = d->flags & YOLO_FLAG_RESIDUAL;
+    if (d->tile == 14 || (d->tile != 13 && d->tile < 16 && (long long)d->h * d->w <= g_wino2_maxpix)) {       // two passes over xi, two workgroups per CU (conv_wino2_f32)
+        const size_t lds2 = (size_t)256 * 68 * 4 + 512;                        // the store staging (> the 64 KiB ring)
+        auto go2 = [&](auto kern) -> int {
+            static LdsOnce once;
+            if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), lds2, "conv_wino2_f32")) return rc;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, s, a);
+            return check_launch("conv_wino2_f32");
+        };
+        YOLO_SWITCH_ACT(d->act, return res ? go2(&conv_wino2_f32<ACT, true>) : go2(&conv_wino2_f32<ACT, false>));
+        return fail(YOLO_ERR_ARG, "conv winograd: activation");
+    }
     const size_t lds = (size_t)WN_SLOTS * WN_STAGE;
     auto go = [&](auto kern) -> int {
         static LdsOnce once;
