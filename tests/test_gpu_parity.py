@@ -1813,6 +1813,41 @@ def test_fp32_winograd_kernel(yt, case):
     assert int(flag.item()) & 2
 
 
+@pytest.mark.parametrize("case", [(2, 10, 10, 128, 256, False), (3, 13, 9, 256, 64, True), (1, 6, 6, 64, 96, True)])
+def test_fp32_winograd_input_gradient(yt, case):
+    """The stride-1 3x3 input gradient on the Winograd kernels: `yolo_pack_weights_dgrad(flip = 1)` appends G g' G^T with
+    g'[ci][co][p][q] = w[co][ci][2-p][2-q], `yolo_conv_fwd_ws` (tile 13 and the default) on it is dx = conv_transpose(dz, w)
+    [+ the gradient already accumulated in dx] - the backward of nn.Conv2d w.r.t. its input (train.py:67). Reference: fp64."""
+    import torch.nn.functional as F
+    from yolo_for_turbines_amd import _lib as L
+    B, H, W, cin, cout, accumulate = case
+    g = torch.Generator().manual_seed(77 + cin + cout + H)
+    lib, dev, st = L.lib(), torch.device("cuda:0"), L.current_stream()
+    coutp = (cout + 31) // 32 * 32
+    dz = torch.zeros((B, H, W, coutp))
+    dz[..., :cout] = torch.randn((B, H, W, cout), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (1.0 / (9 * cin)) ** 0.5
+    dx0 = torch.randn((B, H, W, cin), generator=g)
+    ref = F.conv_transpose2d(dz[..., :cout].double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + dx0.double()
+    wp = torch.empty(lib.yolo_packed_dgrad_bytes(cout, cin, 3, 1, L.F32), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_weights_dgrad(w.to(dev).data_ptr(), wp.data_ptr(), cout, cin, 3, 1, L.F32, st))
+    ones, zeros = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+    dzd = dz.to(dev)
+    for tile in (13, 0, 7 if coutp % 32 == 0 else 4):
+        d = L.ConvDesc(n=B, h=H, w=W, cin=coutp, cout=cin, ksize=3, stride=1, x_ld=coutp, x_off=0, y_ld=cin, y_off=0, r_ld=cin, r_off=0,
+                       act=L.ACT_NONE, out_mode=L.OUT_NHWC, dtype=L.F32, flags=L.FLAG_RESIDUAL if accumulate else 0, tile=tile)
+        need = lib.yolo_conv_workspace_bytes(d)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        dx = dx0.clone().to(dev)
+        L.check(lib.yolo_conv_fwd_ws(d, dzd.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), dx.data_ptr() if accumulate else 0,
+                                     dx.data_ptr(), ws.data_ptr() if need else 0, need, 0, st), "yolo_conv_fwd_ws(dgrad)")
+        torch.cuda.synchronize()
+        err = float((dx.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-5, (tile, err)
+
+
 S2_CASES = [  # (B, H, cin, cout, residual, act, y_ld, y_off): 3x3 stride 2 on conv1_dma_h16 with gathered rows (tile 13)
     (2, 26, 64, 128, False, 1, 128, 0),          # KT = 18; 338 output pixels: three tiles, the last ragged
     (1, 52, 128, 256, False, 2, 256, 0),         # two n tiles

@@ -517,9 +517,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32(const WinoArgs p) {
     auto run_pass = [&](auto PASS) {
         constexpr int pass = decltype(PASS)::value;
         f32x2 fa[8], fb[8];
-        issue(pass, 0, 0);
-        if (nst > 1) issue(pass, 1, 1);
-        if (nst > 2) issue(pass, 2, 2);
+        if constexpr (pass == 0) {           // (pass 1's first stages are requested before pass 0's transform, see below)
+            issue(pass, 0, 0);
+            if (nst > 1) issue(pass, 1, 1);
+            if (nst > 2) issue(pass, 2, 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[8];
 #pragma unroll
@@ -578,6 +580,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32(const WinoArgs p) {
             slot = ns;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the look-ahead reads of the stage after the last
+        __syncthreads();                                     // everybody is done with the ring: pass 1's first stages / the staging may overwrite it
+        if constexpr (pass == 0) {                           // ... and they are requested now: in flight during the transform below
+            issue(1, 0, 0);
+            if (nst > 1) issue(1, 1, 1);
+            if (nst > 2) issue(1, 2, 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // partial output transform. A^T = [1 1 1 0; 0 1 -1 -1]: rows 0, 1 of M give t0 = M0 + M1, t1 = M1; rows 2, 3 t0 = M2, t1 = -M2 - M3
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -599,7 +608,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32(const WinoArgs p) {
                 }
             }
         }
-        __syncthreads();                                     // everybody is done with the ring: pass 1's first stages / the staging may overwrite it
     };
     run_pass(std::integral_constant<int, 0>{});
     run_pass(std::integral_constant<int, 1>{});
